@@ -1,0 +1,63 @@
+"""ctypes binding of libdrakes_hip.so (the C ABI declared in include/drakes_hip.h).
+
+There is no fallback: if the library is missing or a call fails, this raises.  Build it with
+`python -m drakes_amd.build` (hipcc cross-compiles gfx950 without a GPU).
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_long, c_uint32, c_uint64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libdrakes_hip.so')
+
+_P = c_void_p
+
+# name -> argtypes; every function returns int (0 = ok).  Kept in one table so that the CPU test
+# suite can check that the library exports exactly what include/drakes_hip.h declares.
+SIGNATURES = {
+    'drk_step_uniforms': [_P, c_int, c_int, c_uint64, c_uint32, c_uint64, _P],
+    'drk_subs_fwd': [_P, _P, _P, _P, c_int, c_int, _P],
+    'drk_reverse_step_hard': [_P, _P, _P, _P, c_int, c_int, c_float, c_float, c_uint64, c_uint32, c_uint64, _P],
+    'drk_denoise_argmax': [_P, _P, _P, c_int, c_int, _P],
+    'drk_time_embed_fwd': [_P, c_int, _P, _P, _P, _P, _P],
+    'drk_time_bias_fwd': [_P, c_int, _P, _P, c_int, _P, _P],
+    'drk_stem_fwd': [_P, _P, _P, _P, _P, c_int, c_int, _P],
+    'drk_ln_fwd': [_P, _P, c_long, _P, _P, _P, _P, _P, c_int, c_int, _P],
+    'drk_conv_fwd_f32': [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P],
+    'drk_head_out_fwd': [_P, _P, _P, _P, c_int, c_int, _P],
+}
+
+_lib = None
+
+
+class DrakesHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Loads the library once; raises DrakesHipError when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DrakesHipError(
+            f'{LIB_PATH} is missing: run `python -m drakes_amd.build`. '
+            'drakes_amd has no CPU or eager-PyTorch fallback for the hot path.')
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.drk_version.restype = c_int
+    lib.drk_version.argtypes = []
+    lib.drk_last_error.restype = c_char_p
+    lib.drk_last_error.argtypes = []
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = c_int
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise DrakesHipError(f'{name} failed ({rc}): {lib.drk_last_error().decode()}')

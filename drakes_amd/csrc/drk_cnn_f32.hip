@@ -1,0 +1,286 @@
+// fp32 denoiser kernels (CNNModel.forward, models/dnaconv.py:74-110): the exact-arithmetic path
+// used for parity with the fp32 reference and for the fine-tuning forward whose activations
+// are kept for the backward pass.  Channels-last activations [B*L][128].
+//
+// The 128->128 k=9 dilated convolution is an implicit GEMM (M = B*L positions, N = 128,
+// K = 9*128) on the f32-input MFMA v_mfma_f32_32x32x2_f32: bit-for-bit an fp32 fma chain, at
+// the fp32 vector peak (155 TF), with one VGPR per operand per lane.
+#include "drk_common.h"
+#include "../../include/drakes_hip.h"
+
+// ------------------------------------------------------------------------------------ time embedding
+// One workgroup (128 threads) per batch row.  Argument of sin/cos reaches ~4e3 rad, so the
+// accurate sinf/cosf are used (no fast-math intrinsics).
+__global__ void __launch_bounds__(128) k_time_embed(const float* __restrict__ sigma, const float* __restrict__ W,
+                                                    const float* __restrict__ lin_w, const float* __restrict__ lin_b,
+                                                    float* __restrict__ temb) {
+  __shared__ float four[DRK_C];
+  const int b = blockIdx.x, c = threadIdx.x;
+  const float s = sigma[b];
+  const float proj = ((s * W[c & 63]) * 2.0f) * 3.14159274101257324f;  // x*W*2*np.pi, left to right in fp32
+  four[c] = (c < 64) ? sinf(proj) : cosf(proj);
+  __syncthreads();
+  float acc = 0.0f;
+  const float* wr = lin_w + (long)c * DRK_C;
+#pragma unroll 8
+  for (int j = 0; j < DRK_C; ++j) acc += wr[j] * four[j];
+  acc += lin_b[c];
+  temb[(long)b * DRK_C + c] = fmaxf(acc, 0.0f);
+}
+
+// grid (n_layers, nb), 128 threads: tbias[b][layer][c] = dense_w[layer][c][:] . temb[b][:] + dense_b[layer][c]
+__global__ void __launch_bounds__(128) k_time_bias(const float* __restrict__ temb, const float* __restrict__ dense_w,
+                                                   const float* __restrict__ dense_b, float* __restrict__ tbias,
+                                                   int n_layers) {
+  __shared__ float te[DRK_C];
+  const int layer = blockIdx.x, b = blockIdx.y, c = threadIdx.x;
+  te[c] = temb[(long)b * DRK_C + c];
+  __syncthreads();
+  const float* wr = dense_w + ((long)layer * DRK_C + c) * DRK_C;
+  float acc = 0.0f;
+#pragma unroll 8
+  for (int j = 0; j < DRK_C; ++j) acc += wr[j] * te[j];
+  tbias[((long)b * n_layers + layer) * DRK_C + c] = acc + dense_b[layer * DRK_C + c];
+}
+
+// ------------------------------------------------------------------------------------ stem
+// 16 flattened rows per workgroup; thread = (output channel, half of the rows).  The 45 weights
+// of a channel sit in registers; the (one-hot or soft) inputs of rows r0-4 .. r0+19 in LDS.
+#define STEM_ROWS 16
+__global__ void __launch_bounds__(256) k_stem(const int64_t* __restrict__ x, const float* __restrict__ x_soft,
+                                              const float* __restrict__ w_t, const float* __restrict__ bias,
+                                              float* __restrict__ feat, long M, int L) {
+  __shared__ float xs[(STEM_ROWS + 8) * DRK_V];
+  const long r0 = (long)blockIdx.x * STEM_ROWS;
+  for (int i = threadIdx.x; i < (STEM_ROWS + 8) * DRK_V; i += 256) {
+    const long r = r0 - 4 + i / DRK_V;
+    const int v = i % DRK_V;
+    float val = 0.0f;
+    if (r >= 0 && r < M) val = x ? ((int)x[r] == v ? 1.0f : 0.0f) : x_soft[r * DRK_V + v];
+    xs[i] = val;
+  }
+  const int co = threadIdx.x & 127, sub = threadIdx.x >> 7;
+  float w[DRK_TAPS * DRK_V];
+#pragma unroll
+  for (int k = 0; k < DRK_TAPS * DRK_V; ++k) w[k] = w_t[k * DRK_C + co];
+  const float bco = bias[co];
+  __syncthreads();
+  for (int rr = sub * (STEM_ROWS / 2); rr < (sub + 1) * (STEM_ROWS / 2); ++rr) {
+    const long r = r0 + rr;
+    if (r >= M) break;
+    const int p = (int)(r % L);
+    float acc = 0.0f;
+#pragma unroll
+    for (int t = 0; t < DRK_TAPS; ++t) {
+      const int pp = p + t - 4;
+      if (pp >= 0 && pp < L) {
+#pragma unroll
+        for (int v = 0; v < DRK_V; ++v) acc += xs[(rr + t) * DRK_V + v] * w[t * DRK_V + v];
+      }
+    }
+    feat[r * DRK_C + co] = fmaxf(acc + bco, 0.0f);
+  }
+}
+
+// ------------------------------------------------------------------------------------ LayerNorm (+ time bias)
+// 32 lanes per row (one float4 each), 8 rows per 256-thread workgroup.
+__global__ void __launch_bounds__(256) k_ln_fwd(const float* __restrict__ feat, const float* __restrict__ tbias,
+                                                long tb_stride, const float* __restrict__ gamma,
+                                                const float* __restrict__ beta, float* __restrict__ h,
+                                                float* __restrict__ mean_out, float* __restrict__ rstd_out, long M,
+                                                int L) {
+  const int lr = threadIdx.x & 31;
+  const long row = (long)blockIdx.x * 8 + (threadIdx.x >> 5);
+  if (row >= M) return;
+  const long b = row / L;
+  f32x4 v = *(const f32x4*)(feat + row * DRK_C + 4 * lr);
+  if (tbias) v += *(const f32x4*)(tbias + b * tb_stride + 4 * lr);
+  float s = (v[0] + v[1]) + (v[2] + v[3]);
+#pragma unroll
+  for (int o = 16; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+  const float mean = s * (1.0f / DRK_C);
+  const f32x4 d = v - mean;
+  float q = (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+#pragma unroll
+  for (int o = 16; o >= 1; o >>= 1) q += __shfl_xor(q, o);
+  const float rstd = 1.0f / sqrtf(q * (1.0f / DRK_C) + 1e-5f);
+  const f32x4 g = *(const f32x4*)(gamma + 4 * lr), be = *(const f32x4*)(beta + 4 * lr);
+  *(f32x4*)(h + row * DRK_C + 4 * lr) = d * rstd * g + be;
+  if (mean_out && lr == 0) {
+    mean_out[row] = mean;
+    rstd_out[row] = rstd;
+  }
+}
+
+// ------------------------------------------------------------------------------------ conv as implicit GEMM
+// Workgroup = 4 waves = 32*MT rows x 128 output channels; wave w owns channels [32w, 32w+32).
+// Per tap and per group of 8 input channels a lane loads one float4 of A per row tile (its row,
+// channels 8g+4*half..+3) and one float4 of B (its output channel, same input channels), then
+// issues 4 MFMAs per row tile.  Operands come straight from global memory: h rows are re-used by
+// the 4 waves and the 9 taps through L1/L2, the 590 KB of weights stay L2-resident.
+template <int MT>
+__global__ void __launch_bounds__(256) k_conv_f32(const float* __restrict__ h, const float* __restrict__ w_pk,
+                                                  const float* __restrict__ bias, const float* resid, float* out,
+                                                  long M, int L, int taps, int dil, int relu) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int half = lane >> 5, lr = lane & 31;
+  const long r0 = (long)blockIdx.x * (32 * MT);
+  const int co = 32 * w + lr;
+  f32x16 acc[MT];
+  long rows[MT];
+  int pos[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[mt][i] = 0.0f;
+    rows[mt] = r0 + 32 * mt + lr;
+    pos[mt] = (int)(rows[mt] % L);
+  }
+  const int center = taps / 2;
+  for (int t = 0; t < taps; ++t) {
+    const int off = (t - center) * dil;
+    const float* src[MT];
+    bool ok[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int p = pos[mt] + off;
+      ok[mt] = rows[mt] < M && p >= 0 && p < L;
+      src[mt] = h + (rows[mt] + off) * DRK_C + 4 * half;
+    }
+    const float* wsrc = w_pk + (((long)t * 32 + half) * DRK_C + co) * 4;
+#pragma unroll 4
+    for (int g = 0; g < 16; ++g) {
+      const f32x4 b = *(const f32x4*)(wsrc + (long)g * (2 * DRK_C * 4));
+      f32x4 a[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        a[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (ok[mt]) a[mt] = *(const f32x4*)(src[mt] + 8 * g);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+          acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][j], b[j], acc[mt], 0, 0, 0);
+    }
+  }
+  const float bco = bias[co];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const long row = r0 + 32 * mt + (i & 3) + 8 * (i >> 2) + 4 * half;
+      if (row < M) {
+        float v = acc[mt][i] + bco;
+        if (relu) v = fmaxf(v, 0.0f);
+        if (resid) v += resid[row * DRK_C + co];
+        out[row * DRK_C + co] = v;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ final 128->5 projection
+// 8 lanes per row; lane s takes float4 chunks s, s+8, s+16, s+24 of the row (coalesced), reduces
+// over the 8 lanes by shuffles; lanes 0..4 of the group store one logit each.
+__global__ void __launch_bounds__(256) k_head_out(const float* __restrict__ y, const float* __restrict__ w,
+                                                  const float* __restrict__ bias, float* __restrict__ logits, long M) {
+  __shared__ float ws[DRK_V * DRK_C];
+  for (int i = threadIdx.x; i < DRK_V * DRK_C; i += 256) ws[i] = w[i];
+  __syncthreads();
+  const int s = threadIdx.x & 7;
+  const long row = (long)blockIdx.x * 32 + (threadIdx.x >> 3);
+  float part[DRK_V] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  if (row < M) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int ch = 4 * (s + 8 * c);
+      const f32x4 a = *(const f32x4*)(y + row * DRK_C + ch);
+#pragma unroll
+      for (int v = 0; v < DRK_V; ++v) {
+        const f32x4 ww = *(const f32x4*)(ws + v * DRK_C + ch);
+        part[v] += (a[0] * ww[0] + a[1] * ww[1]) + (a[2] * ww[2] + a[3] * ww[3]);
+      }
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < DRK_V; ++v) {
+    part[v] += __shfl_xor(part[v], 4);
+    part[v] += __shfl_xor(part[v], 2);
+    part[v] += __shfl_xor(part[v], 1);
+  }
+  if (row < M && s < DRK_V) {
+    float o = part[0];
+#pragma unroll
+    for (int v = 1; v < DRK_V; ++v) o = (s == v) ? part[v] : o;
+    logits[row * DRK_V + s] = o + bias[s];
+  }
+}
+
+// ------------------------------------------------------------------------------------ C ABI
+#define ARGCHECK(cond, name) \
+  if (!(cond)) return drk_set_error_msg(DRK_EINVAL, name ": bad arguments")
+
+extern "C" int drk_time_embed_fwd(const float* sigma, int nb, const float* W, const float* lin_w, const float* lin_b,
+                                  float* temb, void* stream) {
+  ARGCHECK(sigma && W && lin_w && lin_b && temb && nb >= 0, "drk_time_embed_fwd");
+  if (nb == 0) return DRK_OK;
+  hipLaunchKernelGGL(k_time_embed, dim3(nb), dim3(128), 0, (hipStream_t)stream, sigma, W, lin_w, lin_b, temb);
+  DRK_CHECK_LAUNCH();
+  return DRK_OK;
+}
+
+extern "C" int drk_time_bias_fwd(const float* temb, int nb, const float* dense_w, const float* dense_b, int n_layers,
+                                 float* tbias, void* stream) {
+  ARGCHECK(temb && dense_w && dense_b && tbias && nb >= 0 && n_layers > 0, "drk_time_bias_fwd");
+  if (nb == 0) return DRK_OK;
+  hipLaunchKernelGGL(k_time_bias, dim3(n_layers, nb), dim3(128), 0, (hipStream_t)stream, temb, dense_w, dense_b, tbias,
+                     n_layers);
+  DRK_CHECK_LAUNCH();
+  return DRK_OK;
+}
+
+extern "C" int drk_stem_fwd(const int64_t* x, const float* x_soft, const float* w_t, const float* bias, float* feat,
+                            int B, int L, void* stream) {
+  ARGCHECK((x || x_soft) && w_t && bias && feat && B >= 0 && L > 0, "drk_stem_fwd");
+  const long M = (long)B * L;
+  if (M == 0) return DRK_OK;
+  hipLaunchKernelGGL(k_stem, dim3((unsigned)((M + STEM_ROWS - 1) / STEM_ROWS)), dim3(256), 0, (hipStream_t)stream, x,
+                     x_soft, w_t, bias, feat, M, L);
+  DRK_CHECK_LAUNCH();
+  return DRK_OK;
+}
+
+extern "C" int drk_ln_fwd(const float* feat, const float* tbias, long tbias_bstride, const float* gamma,
+                          const float* beta, float* h, float* mean, float* rstd, int B, int L, void* stream) {
+  ARGCHECK(feat && gamma && beta && h && B >= 0 && L > 0 && (!mean == !rstd), "drk_ln_fwd");
+  const long M = (long)B * L;
+  if (M == 0) return DRK_OK;
+  hipLaunchKernelGGL(k_ln_fwd, dim3((unsigned)((M + 7) / 8)), dim3(256), 0, (hipStream_t)stream, feat, tbias,
+                     tbias_bstride, gamma, beta, h, mean, rstd, M, L);
+  DRK_CHECK_LAUNCH();
+  return DRK_OK;
+}
+
+extern "C" int drk_conv_fwd_f32(const float* h, const float* w_pk, const float* bias, const float* resid, float* out,
+                                int B, int L, int taps, int dilation, int relu, void* stream) {
+  ARGCHECK(h && w_pk && bias && out && B >= 0 && L > 0 && taps >= 1 && (taps & 1) && dilation >= 0,
+           "drk_conv_fwd_f32");
+  const long M = (long)B * L;
+  if (M == 0) return DRK_OK;
+  hipLaunchKernelGGL(k_conv_f32<2>, dim3((unsigned)((M + 63) / 64)), dim3(256), 0, (hipStream_t)stream, h, w_pk, bias,
+                     resid, out, M, L, taps, dilation, relu);
+  DRK_CHECK_LAUNCH();
+  return DRK_OK;
+}
+
+extern "C" int drk_head_out_fwd(const float* y, const float* w, const float* bias, float* logits, int B, int L,
+                                void* stream) {
+  ARGCHECK(y && w && bias && logits && B >= 0 && L > 0, "drk_head_out_fwd");
+  const long M = (long)B * L;
+  if (M == 0) return DRK_OK;
+  hipLaunchKernelGGL(k_head_out, dim3((unsigned)((M + 31) / 32)), dim3(256), 0, (hipStream_t)stream, y, w, bias, logits,
+                     M);
+  DRK_CHECK_LAUNCH();
+  return DRK_OK;
+}

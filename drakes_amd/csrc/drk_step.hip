@@ -1,0 +1,162 @@
+// Reverse-step kernels: SUBS parameterisation, absorbing-diffusion posterior, Gumbel-argmax,
+// carry-over unmasking.  HBM-bound elementwise work: one lane per sequence position, 5 logits
+// (20 B) + token (8 B) in, token (8 B) out; uniforms either read (20 B) or generated in-register
+// by Philox.  Logits of consecutive lanes are contiguous, so every wave-load is a dense
+// 1280-byte span; tokens are dense 512-byte spans.
+#include "drk_common.h"
+#include "../../include/drakes_hip.h"
+
+#include <stdio.h>
+#include <string.h>
+
+// ------------------------------------------------------------------------------------ errors
+static thread_local char g_err[256] = "";
+
+int drk_set_error(hipError_t e, const char* where) {
+  snprintf(g_err, sizeof(g_err), "%s: %s", where, hipGetErrorString(e));
+  return DRK_EHIP;
+}
+int drk_set_error_msg(int code, const char* msg) {
+  snprintf(g_err, sizeof(g_err), "%s", msg);
+  return code;
+}
+extern "C" const char* drk_last_error(void) { return g_err; }
+extern "C" int drk_version(void) { return 100; }
+
+// ------------------------------------------------------------------------------------ kernels
+__device__ __forceinline__ void load5(const float* __restrict__ p, long i, float v[DRK_V]) {
+#pragma unroll
+  for (int k = 0; k < DRK_V; ++k) v[k] = p[i * DRK_V + k];
+}
+
+__device__ __forceinline__ int soft_argmax(const float v[DRK_V]) {
+  int best = 0;
+#pragma unroll
+  for (int k = 1; k < DRK_V; ++k)
+    if (v[k] > v[best]) best = k;
+  return best;
+}
+
+__global__ void __launch_bounds__(256) k_step_uniforms(float* __restrict__ u, long n, int L, uint64_t seed,
+                                                       uint32_t step, uint64_t sample_offset) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float uu[DRK_V];
+    drk_step_uniforms(seed, step, sample_offset + (uint64_t)(i / L), (uint32_t)(i % L), uu);
+#pragma unroll
+    for (int k = 0; k < DRK_V; ++k) u[i * DRK_V + k] = uu[k];
+  }
+}
+
+__global__ void __launch_bounds__(256) k_subs_fwd(const float* __restrict__ logits, const int64_t* __restrict__ x,
+                                                  const float* __restrict__ x_soft, float* __restrict__ logp, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float lg[DRK_V], lp[DRK_V];
+    load5(logits, i, lg);
+    int tok;
+    if (x) {
+      tok = (int)x[i];
+    } else {
+      float xs[DRK_V];
+      load5(x_soft, i, xs);
+      tok = soft_argmax(xs);
+    }
+    drk_subs_logp(lg, tok, lp);
+#pragma unroll
+    for (int k = 0; k < DRK_V; ++k) logp[i * DRK_V + k] = lp[k];
+  }
+}
+
+template <bool INJECT>
+__global__ void __launch_bounds__(256)
+    k_reverse_step_hard(const float* __restrict__ logits, const int64_t* x,  // x_next may alias x
+                        const float* __restrict__ uniforms, int64_t* x_next, long n, int L, float mc_t,
+                        float mc_s, uint64_t seed, uint32_t step, uint64_t sample_offset) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int tok = (int)x[i];
+    int out = tok;
+    if (tok == DRK_MASK) {  // carry-over: an unmasked position keeps its token (:482-486)
+      float lg[DRK_V], lp[DRK_V], q[DRK_V], u[DRK_V];
+      load5(logits, i, lg);
+      if (INJECT)
+        load5(uniforms, i, u);
+      else
+        drk_step_uniforms(seed, step, sample_offset + (uint64_t)(i / L), (uint32_t)(i % L), u);
+      drk_subs_logp(lg, DRK_MASK, lp);
+      drk_posterior(lp, mc_t, mc_s, q);
+      out = drk_gumbel_argmax(q, u);
+    }
+    x_next[i] = out;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_denoise_argmax(const float* __restrict__ logits, const int64_t* __restrict__ x,
+                                                        int64_t* __restrict__ x_out, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int tok = (int)x[i];
+    float lg[DRK_V], lp[DRK_V];
+    load5(logits, i, lg);
+    drk_subs_logp(lg, tok, lp);
+    int best = 0;
+#pragma unroll
+    for (int k = 1; k < DRK_V - 1; ++k)
+      if (lp[k] > lp[best]) best = k;
+    x_out[i] = best;
+  }
+}
+
+// ------------------------------------------------------------------------------------ C ABI
+static inline int grid_for(long n) {
+  long g = (n + 255) / 256;
+  if (g > 2048) g = 2048;  // 256 CUs x 8 blocks, grid-stride beyond
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+extern "C" int drk_step_uniforms(float* u, int B, int L, uint64_t seed, uint32_t step, uint64_t sample_offset,
+                                 void* stream) {
+  if (!u || B < 0 || L <= 0) return drk_set_error_msg(DRK_EINVAL, "drk_step_uniforms: bad arguments");
+  const long n = (long)B * L;
+  if (n == 0) return DRK_OK;
+  hipLaunchKernelGGL(k_step_uniforms, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, u, n, L, seed, step,
+                     sample_offset);
+  DRK_CHECK_LAUNCH();
+  return DRK_OK;
+}
+
+extern "C" int drk_subs_fwd(const float* logits, const int64_t* x, const float* x_soft, float* logp, int B, int L,
+                            void* stream) {
+  if (!logits || !logp || (!x && !x_soft) || B < 0 || L <= 0)
+    return drk_set_error_msg(DRK_EINVAL, "drk_subs_fwd: bad arguments");
+  const long n = (long)B * L;
+  if (n == 0) return DRK_OK;
+  hipLaunchKernelGGL(k_subs_fwd, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, logits, x, x_soft, logp, n);
+  DRK_CHECK_LAUNCH();
+  return DRK_OK;
+}
+
+extern "C" int drk_reverse_step_hard(const float* logits, const int64_t* x, const float* uniforms, int64_t* x_next,
+                                     int B, int L, float mc_t, float mc_s, uint64_t seed, uint32_t step,
+                                     uint64_t sample_offset, void* stream) {
+  if (!logits || !x || !x_next || B < 0 || L <= 0)
+    return drk_set_error_msg(DRK_EINVAL, "drk_reverse_step_hard: bad arguments");
+  const long n = (long)B * L;
+  if (n == 0) return DRK_OK;
+  if (uniforms)
+    hipLaunchKernelGGL(k_reverse_step_hard<true>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, logits, x,
+                       uniforms, x_next, n, L, mc_t, mc_s, seed, step, sample_offset);
+  else
+    hipLaunchKernelGGL(k_reverse_step_hard<false>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, logits, x,
+                       uniforms, x_next, n, L, mc_t, mc_s, seed, step, sample_offset);
+  DRK_CHECK_LAUNCH();
+  return DRK_OK;
+}
+
+extern "C" int drk_denoise_argmax(const float* logits, const int64_t* x, int64_t* x_out, int B, int L, void* stream) {
+  if (!logits || !x || !x_out || B < 0 || L <= 0)
+    return drk_set_error_msg(DRK_EINVAL, "drk_denoise_argmax: bad arguments");
+  const long n = (long)B * L;
+  if (n == 0) return DRK_OK;
+  hipLaunchKernelGGL(k_denoise_argmax, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, logits, x, x_out, n);
+  DRK_CHECK_LAUNCH();
+  return DRK_OK;
+}

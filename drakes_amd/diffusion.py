@@ -1,0 +1,171 @@
+"""Drop-in for the sampling surface of the reference `Diffusion` class
+(/root/reference/drakes_dna/diffusion_gosai_update.py:74-144, :243-275, :438-440, :462-486,
+:506-630), running on hand-written gfx950 kernels.
+
+Same constructor, method names (leading underscores included), argument meaning, return
+shapes/dtypes and state_dict keys.  What is NOT here (pre-training hooks, EMA, the guided
+baselines, the gReLU reward oracle) is listed in DESIGN.md "out of scope".
+
+Differences a caller can see, all additive:
+  * randomness: the reference calls torch.rand_like per step; here each step's uniforms are a
+    counter-based function of (seed, step, global sample index, position, class).  `seed`
+    defaults to a draw from torch's CPU generator, so `torch.manual_seed(s)` still makes a run
+    reproducible.  `uniforms=` injects explicit noise (tests), `sample_offset=` is the global
+    index of row 0 (data-parallel shards draw the noise of their own rows).
+  * `hip_dtype` ('fp32' | 'bf16') selects the exact-fp32 kernels or the bf16-MFMA fast path.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import noise_schedule, ops
+from .models import dnaconv
+
+
+class Diffusion(nn.Module):
+    def __init__(self, config, eval=False):
+        super().__init__()
+        if eval:
+            raise NotImplementedError('eval=True loads the gReLU reward oracle and the Gosai dataset '
+                                      '(reference :133-139); both are outside the sampling hot path')
+        self.config = config
+        self.vocab_size = 4
+        self.sampler = self.config.sampling.predictor
+        self.mask_index = self.vocab_size
+        self.vocab_size += 1
+        self.parameterization = self.config.parameterization
+        if self.config.backbone == 'cnn':
+            self.backbone = dnaconv.CNNModel(self.config.model, alphabet_size=self.vocab_size, num_cls=3)
+        else:
+            raise ValueError(f'Unknown backbone: {self.config.backbone}')
+        self.T = self.config.T
+        self.subs_masking = getattr(self.config, 'subs_masking', False)
+        self.noise = noise_schedule.get_noise(self.config)
+        self.time_conditioning = self.config.time_conditioning
+        self.neg_infinity = -1000000.0
+        self.hip_dtype = 'fp32'
+        self._validate_configuration()
+        self._work = {}
+
+    def _validate_configuration(self):
+        assert self.parameterization == 'subs'
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    @property
+    def dtype(self):
+        return torch.float32
+
+    # ------------------------------------------------------------------ forward
+    def _process_sigma(self, sigma):
+        """reference :255-264"""
+        if sigma.ndim > 1:
+            sigma = sigma.squeeze(-1)
+        if not self.time_conditioning:
+            sigma = torch.zeros_like(sigma)
+        assert sigma.ndim == 1, sigma.shape
+        return sigma
+
+    def _subs_parameterization(self, logits, xt):
+        """reference :243-253 (one fused kernel; writes into `logits` like the reference)."""
+        xt = xt if xt.dtype == torch.int64 else xt.contiguous()
+        return ops.subs_fwd(logits, xt, out=logits)
+
+    def forward(self, x, sigma):
+        """Returns log score — reference :266-275."""
+        sigma = self._process_sigma(sigma)
+        logits = self.backbone(x, sigma)
+        return self._subs_parameterization(logits=logits, xt=x)
+
+    # ------------------------------------------------------------------ sampling helpers
+    def _sample_prior(self, *batch_dims):
+        """reference :438-440"""
+        return self.mask_index * torch.ones(*batch_dims, dtype=torch.int64)
+
+    def _draw_seed(self):
+        return int(torch.randint(0, 2 ** 62, (1,)).item())
+
+    def _shared_time_bias(self, sigma_scalar):
+        """[1, n_layers, 128] time biases for one sigma shared by the whole batch."""
+        s = torch.full((1,), float(sigma_scalar), dtype=torch.float32, device=self.device)
+        if not self.time_conditioning:
+            s.zero_()
+        return self.backbone.time_bias(s)
+
+    def _ddpm_update(self, x, t, dt, return_process=False, *, seed=None, step=0, sample_offset=0, uniforms=None):
+        """One hard reverse step — reference :462-486.  `t` [B,1] (all rows equal, as _sample builds it)."""
+        sigma_t, _ = self.noise(t)
+        sigma_s, _ = self.noise(t - dt)
+        if sigma_t.ndim > 1:
+            sigma_t = sigma_t.squeeze(-1)
+        if sigma_s.ndim > 1:
+            sigma_s = sigma_s.squeeze(-1)
+        move_chance_t = 1 - torch.exp(-sigma_t)
+        move_chance_s = 1 - torch.exp(-sigma_s)
+        mc_t, mc_s = float(move_chance_t[0]), float(move_chance_s[0])
+        if not (bool((move_chance_t == move_chance_t[0]).all()) and bool((move_chance_s == move_chance_s[0]).all())):
+            raise NotImplementedError('per-row timesteps: the fused step takes one (mc_t, mc_s) per call')
+        if seed is None and uniforms is None:
+            seed = self._draw_seed()
+        with torch.no_grad():
+            logits = self.backbone(x, self._process_sigma(sigma_t))
+            x_next = ops.reverse_step_hard(logits, x.contiguous(), mc_t, mc_s, seed or 0, step, sample_offset, uniforms)
+        if return_process:
+            copy_flag = (x != self.mask_index).to(x.dtype)
+            return x_next, x, sigma_t, move_chance_t[:, None, None], copy_flag
+        return x_next
+
+    @torch.no_grad()
+    def _sample(self, num_steps=None, eps=1e-5, eval_sp_size=None, *, seed=None, sample_offset=0, uniforms=None):
+        """Generate samples from the model — reference :506-550 (ddpm predictor).
+
+        uniforms: optional callable step -> float32 [B,L,5] device tensor replacing the in-kernel
+        Philox draw (noise injection for parity tests)."""
+        if eval_sp_size is None:
+            batch = self.config.loader.eval_batch_size
+        else:
+            batch = eval_sp_size
+        if self.sampler != 'ddpm':
+            raise NotImplementedError(f"sampling.predictor={self.sampler!r}: only 'ddpm' is on the hot path")
+        if num_steps is None:
+            num_steps = self.config.sampling.steps
+        L = self.config.model.length
+        dev = self.device
+        if seed is None:
+            seed = self._draw_seed()
+        table, sigma_last, _, _ = noise_schedule.step_table(self.noise, num_steps, eps)
+        table = table.tolist()
+        x = self._sample_prior(batch, L).to(dev)
+        if batch == 0:
+            return x
+        if self.hip_dtype == 'bf16':
+            from . import fastpath
+            return fastpath.sample_bf16(self, x, table, float(sigma_last), seed, sample_offset, uniforms)
+        bb = self.backbone
+        shared = None if self.time_conditioning else self._shared_time_bias(0.0)
+        for i in range(num_steps):
+            _, sigma_t, mc_t, mc_s = table[i]
+            tb = shared if shared is not None else self._shared_time_bias(sigma_t)
+            logits = bb.forward_f32(x, tb, 0, self._work)
+            u = uniforms(i) if uniforms is not None else None
+            ops.reverse_step_hard(logits, x, mc_t, mc_s, seed, i, sample_offset, u, out=x)
+        if self.config.sampling.noise_removal:
+            tb = shared if shared is not None else self._shared_time_bias(float(sigma_last))
+            logits = bb.forward_f32(x, tb, 0, self._work)
+            x = ops.denoise_argmax(logits, x)
+        return x
+
+    # ------------------------------------------------------------------ fine-tuning sampler
+    def _ddpm_update_finetune_gradient(self, x, t, dt, copy_flag_temp, return_process=False, **kw):
+        from . import finetune
+        return finetune.ddpm_update_finetune_gradient(self, x, t, dt, copy_flag_temp, return_process, **kw)
+
+    def _sample_finetune_gradient(self, num_steps=None, eps=1e-5, eval_sp_size=None, copy_flag_temp=None, **kw):
+        """reference :589-630"""
+        from . import finetune
+        return finetune.sample_finetune_gradient(self, num_steps, eps, eval_sp_size, copy_flag_temp, **kw)
+
+    # north_star spells the method without the underscore; harmless alias
+    sample_finetune_gradient = _sample_finetune_gradient

@@ -1,0 +1,138 @@
+"""CNN denoiser of DRAKES (DNA) on hand-written gfx950 kernels.
+
+Same constructor, parameter names and state_dict keys as the reference `CNNModel`
+(/root/reference/drakes_dna/models/dnaconv.py:37-110), so reference checkpoints load with
+strict=True.  The torch modules below only HOLD parameters; `forward` runs the HIP kernels
+(drakes_amd/csrc) on channels-last activations [B, L, 128].
+
+Scope: the sampling configuration (clean_data=False, cls_free_guidance=False,
+classifier=False, hidden_dim=128); anything else raises.
+"""
+import copy
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+
+DILATIONS = (1, 1, 4, 16, 64)   # dnaconv.py:53-57; padding = 4 * dilation ('same')
+
+
+class GaussianFourierProjection(nn.Module):
+    """Holds the fixed random frequencies W (dnaconv.py:8-21); evaluated inside drk_time_embed_fwd."""
+
+    def __init__(self, embed_dim, scale=30.):
+        super().__init__()
+        self.W = nn.Parameter(torch.randn(embed_dim // 2) * scale, requires_grad=False)
+
+
+class Dense(nn.Module):
+    def __init__(self, input_dim, output_dim):
+        super().__init__()
+        self.dense = nn.Linear(input_dim, output_dim)
+
+
+class CNNModel(nn.Module):
+    def __init__(self, args, alphabet_size, num_cls, classifier=False):
+        super().__init__()
+        if classifier or getattr(args, 'clean_data', False) or getattr(args, 'cls_free_guidance', False):
+            raise NotImplementedError('drakes_amd.CNNModel covers the sampling configuration only '
+                                      '(clean_data=False, cls_free_guidance=False, classifier=False)')
+        if args.hidden_dim != ops.C:
+            raise NotImplementedError(f'the gfx950 kernels are written for hidden_dim={ops.C}, got {args.hidden_dim}')
+        if alphabet_size != ops.V:
+            raise NotImplementedError(f'alphabet_size must be {ops.V} (A,C,G,T,mask)')
+        if getattr(args, 'dropout', 0.0) != 0.0:
+            raise NotImplementedError('dropout > 0 is not implemented (the shipped config uses 0.0)')
+        self.alphabet_size = alphabet_size
+        self.args = args
+        self.classifier = classifier
+        self.num_cls = num_cls
+        C = args.hidden_dim
+        self.linear = nn.Conv1d(alphabet_size, C, kernel_size=9, padding=4)
+        self.time_embedder = nn.Sequential(GaussianFourierProjection(embed_dim=C), nn.Linear(C, C))
+        self.num_layers = 5 * args.num_cnn_stacks
+        protos = [nn.Conv1d(C, C, kernel_size=9, dilation=d, padding=4 * d) for d in DILATIONS]
+        # each layer type repeated num_cnn_stacks times consecutively, as deep copies (dnaconv.py:58)
+        self.convs = nn.ModuleList([copy.deepcopy(p) for p in protos for _ in range(args.num_cnn_stacks)])
+        self.time_layers = nn.ModuleList([Dense(C, C) for _ in range(self.num_layers)])
+        self.norms = nn.ModuleList([nn.LayerNorm(C) for _ in range(self.num_layers)])
+        self.final_conv = nn.Sequential(nn.Conv1d(C, C, kernel_size=1), nn.ReLU(),
+                                        nn.Conv1d(C, alphabet_size, kernel_size=1))
+        self.dropout = nn.Dropout(args.dropout)
+        self._packed = None
+        self._packed_key = None
+
+    # ------------------------------------------------------------------ packed weights
+    def dilation(self, i):
+        return DILATIONS[i // self.args.num_cnn_stacks]
+
+    def _weights_key(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def packed(self):
+        """Kernel-layout copies of the weights; rebuilt when any parameter changed in place
+        (optimizer step, load_state_dict) or moved."""
+        key = self._weights_key()
+        if self._packed is None or key != self._packed_key:
+            with torch.no_grad():
+                n = self.num_layers
+                self._packed = {
+                    'stem_w': ops.pack_stem_weight(self.linear.weight),
+                    'stem_b': self.linear.bias.detach().contiguous(),
+                    'four_W': self.time_embedder[0].W.detach().contiguous(),
+                    'temb_w': self.time_embedder[1].weight.detach().contiguous(),
+                    'temb_b': self.time_embedder[1].bias.detach().contiguous(),
+                    'dense_w': torch.stack([self.time_layers[i].dense.weight.detach() for i in range(n)]).contiguous(),
+                    'dense_b': torch.stack([self.time_layers[i].dense.bias.detach() for i in range(n)]).contiguous(),
+                    'ln_g': [self.norms[i].weight.detach().contiguous() for i in range(n)],
+                    'ln_b': [self.norms[i].bias.detach().contiguous() for i in range(n)],
+                    'conv_w': [ops.pack_conv_weight_f32(self.convs[i].weight) for i in range(n)],
+                    'conv_b': [self.convs[i].bias.detach().contiguous() for i in range(n)],
+                    'head0_w': ops.pack_conv_weight_f32(self.final_conv[0].weight),
+                    'head0_b': self.final_conv[0].bias.detach().contiguous(),
+                    'head2_w': self.final_conv[2].weight.detach().reshape(self.alphabet_size, -1).contiguous(),
+                    'head2_b': self.final_conv[2].bias.detach().contiguous(),
+                }
+            self._packed_key = key
+        return self._packed
+
+    # ------------------------------------------------------------------ forward
+    def time_bias(self, t):
+        """[nb, n_layers, 128] per-layer time biases for sigma `t` [nb] (dnaconv.py:82,92)."""
+        pk = self.packed()
+        temb = ops.time_embed_fwd(t.contiguous(), pk['four_W'], pk['temb_w'], pk['temb_b'])
+        return ops.time_bias_fwd(temb, pk['dense_w'], pk['dense_b'])
+
+    def forward_f32(self, seq, tbias, tb_stride, work=None):
+        """Exact-fp32 kernels.  seq int64 [B,L] or float32 [B,L,5]; tbias [nb,n_layers,128]
+        with `tb_stride` floats between batch rows (0 when one row serves the batch)."""
+        pk = self.packed()
+        B, L = seq.shape[0], seq.shape[1]
+        if work is None:
+            work = {}
+        def buf(name, *shape):
+            t = work.get(name)
+            if t is None or t.shape != torch.Size(shape):
+                t = torch.empty(*shape, dtype=torch.float32, device=seq.device)
+                work[name] = t
+            return t
+        feat = ops.stem_fwd(seq, pk['stem_w'], pk['stem_b'], out=buf('feat', B, L, ops.C))
+        h = buf('h', B, L, ops.C)
+        for i in range(self.num_layers):
+            ops.ln_fwd(feat, tbias[0, i], tb_stride, pk['ln_g'][i], pk['ln_b'][i], out=h)
+            ops.conv_fwd_f32(h, pk['conv_w'][i], pk['conv_b'][i], feat, self.dilation(i), relu=True, out=feat)
+        ops.conv_fwd_f32(feat, pk['head0_w'], pk['head0_b'], None, 0, relu=True, out=h)
+        return ops.head_out_fwd(h, pk['head2_w'], pk['head2_b'], out=buf('logits', B, L, ops.V))
+
+    def forward(self, seq, t, cls=None, return_embedding=False):
+        """Reference signature (dnaconv.py:74).  Returns logits [B, L, 5] fp32."""
+        if cls is not None or return_embedding:
+            raise NotImplementedError('cls / return_embedding belong to the classifier and CFG variants')
+        if seq.dtype != torch.int64 and not (seq.ndim > 2 and seq.shape[-1] == self.alphabet_size):
+            seq = seq.long()
+        if torch.is_grad_enabled() and (seq.requires_grad or any(p.requires_grad for p in self.parameters())):
+            from ..autograd import backbone_with_grad
+            return backbone_with_grad(self, seq, t)
+        tbias = self.time_bias(t.to(torch.float32))
+        return self.forward_f32(seq.contiguous(), tbias, tbias.stride(0))

@@ -1,0 +1,96 @@
+/*
+ * drakes_hip.h — C ABI of libdrakes_hip.so: hand-written gfx950 (MI355X) kernels for the
+ * masked-diffusion reverse-sampling hot path of DRAKES (DNA).
+ *
+ * The reference has no FFI: its boundary is the Python method surface of `Diffusion`
+ * (drakes_dna/diffusion_gosai_update.py).  Each entry point below names the reference code it
+ * replaces; drakes_amd/diffusion.py re-assembles them behind the reference's method names and
+ * INTEGRATION.md shows the ctypes stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller; nothing here allocates, frees or
+ *     synchronises; `stream` is a hipStream_t passed as void* (NULL = the null stream);
+ *   - return 0 on success, a negative DRK_E* code otherwise (drk_last_error() has the text);
+ *   - activations are channels-last fp32 [B][L][128]; tokens are int64 [B][L] with ids
+ *     A,C,G,T = 0..3 and mask = 4 (dataloader_gosai.py:11, diffusion_gosai_update.py:82-88);
+ *   - safe to call concurrently on distinct streams (no global mutable state except the
+ *     thread-local error string).
+ *
+ * Noise convention (the build's own; the reference draws torch.rand_like at :27/:33): when the
+ * `uniforms` argument of a step function is NULL the kernel evaluates Philox4x32-10 with
+ *   counter = (position, sample & 0xffffffff, step, 0x44524B53 ^ (sample >> 32)), key = seed,
+ *   U[v] = (r[v] >> 8) * 2^-24 (v<4),  U[4] = ((r0&255)<<16 | (r1&255)<<8 | (r2&255)) * 2^-24,
+ * where sample = sample_offset + row.  Rows therefore draw the same noise however the batch
+ * is sharded over GPUs.
+ */
+#ifndef DRAKES_HIP_H
+#define DRAKES_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DRK_OK 0
+#define DRK_EINVAL (-1)   /* bad shape / null pointer / unsupported size */
+#define DRK_EHIP (-2)     /* a HIP runtime call or launch failed */
+
+int drk_version(void);
+const char* drk_last_error(void);
+
+/* ---- noise -------------------------------------------------------------------------------- */
+/* Writes the step's uniforms, float32 [B][L][5].  Test/injection helper: what the step kernels
+ * evaluate in-register when `uniforms == NULL`.  Stands in for torch.rand_like at
+ * diffusion_gosai_update.py:27,33. */
+int drk_step_uniforms(float* u, int B, int L, uint64_t seed, uint32_t step, uint64_t sample_offset,
+                      void* stream);
+
+/* ---- reverse step (hard) ------------------------------------------------------------------ */
+/* SUBS log-probs from raw backbone logits: Diffusion._subs_parameterization,
+ * diffusion_gosai_update.py:243-253.  logits,logp float32 [B][L][5] (may alias); x int64 [B][L],
+ * or NULL with x_soft float32 [B][L][5] (held token = argmax, :247-249). */
+int drk_subs_fwd(const float* logits, const int64_t* x, const float* x_soft, float* logp, int B, int L,
+                 void* stream);
+
+/* One hard reverse step from raw logits: _subs_parameterization + the tail of _ddpm_update
+ * (:478-486) + _sample_categorical (:24-28).  x_next may alias x.  mc_t/mc_s are the step's
+ * move chances (all batch rows equal, :527-528). */
+int drk_reverse_step_hard(const float* logits, const int64_t* x, const float* uniforms, int64_t* x_next,
+                          int B, int L, float mc_t, float mc_s, uint64_t seed, uint32_t step,
+                          uint64_t sample_offset, void* stream);
+
+/* Noise-removal: SUBS, then argmax over the 4 nucleotides — _sample, :541-549. */
+int drk_denoise_argmax(const float* logits, const int64_t* x, int64_t* x_out, int B, int L, void* stream);
+
+/* ---- denoiser (CNNModel.forward, models/dnaconv.py:74-110), fp32 ---------------------------- */
+/* relu(Linear(GaussianFourierProjection(sigma))) — dnaconv.py:19-21,50,82.
+ * sigma [nb]; W [64]; lin_w [128][128]; lin_b [128]; temb [nb][128]. */
+int drk_time_embed_fwd(const float* sigma, int nb, const float* W, const float* lin_w, const float* lin_b,
+                       float* temb, void* stream);
+/* The n_layers per-layer Dense projections of the time embedding — dnaconv.py:59,92.
+ * dense_w [n_layers][128][128]; dense_b [n_layers][128]; tbias [nb][n_layers][128]. */
+int drk_time_bias_fwd(const float* temb, int nb, const float* dense_w, const float* dense_b, int n_layers,
+                      float* tbias, void* stream);
+/* Stem: relu(Conv1d(5->128,k=9,pad=4)(one_hot(x))) — dnaconv.py:76-77,83-84.
+ * x int64 [B][L] or (x == NULL) x_soft float32 [B][L][5]; w_t [9][5][128] (= weight.permute(2,1,0));
+ * feat [B][L][128]. */
+int drk_stem_fwd(const int64_t* x, const float* x_soft, const float* w_t, const float* bias, float* feat,
+                 int B, int L, void* stream);
+/* h = LayerNorm_128(feat + tbias[:, None, :]) — dnaconv.py:90-95.  tbias row stride
+ * `tbias_bstride` floats between batch rows (0 = one row shared by the whole batch).
+ * mean/rstd [B*L] are optional outputs for the backward pass. */
+int drk_ln_fwd(const float* feat, const float* tbias, long tbias_bstride, const float* gamma,
+               const float* beta, float* h, float* mean, float* rstd, int B, int L, void* stream);
+/* feat_out = relu(Conv1d(128->128,k=taps,dilation)(h) + bias) [+ resid] — dnaconv.py:96-98 and,
+ * with taps=1 and resid=NULL, final_conv.0 + ReLU (:61-62,101).  Exact fp32 (f32-input MFMA).
+ * w_pk [taps][32][128][4]: w_pk[t][g][co][q] = weight[co][4g+q][t]. */
+int drk_conv_fwd_f32(const float* h, const float* w_pk, const float* bias, const float* resid, float* out,
+                     int B, int L, int taps, int dilation, int relu, void* stream);
+/* logits = Conv1d(128->5,k=1)(y) — dnaconv.py:63,101-102.  w [5][128]; logits [B][L][5]. */
+int drk_head_out_fwd(const float* y, const float* w, const float* bias, float* logits, int B, int L,
+                     void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

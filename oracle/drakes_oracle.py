@@ -1,0 +1,257 @@
+"""TEST INFRASTRUCTURE — the CPU oracle for the DRAKES reverse-sampling hot path.
+
+A functional, CPU-only (torch fp32) restatement of the reference algorithm.  It is
+the CHECKER for the HIP path: only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg may import it.  Nothing under drakes_amd/ imports it, and the
+product path raises when the HIP library is missing instead of coming here.
+
+Pinned: oracle/make_golden.py imports the real reference class (with stand-ins for
+the third-party packages this image lacks) and checks every function below against
+it with the same weights and the same injected uniforms, then writes the fixtures
+in tests/golden/.  tests/test_oracle_golden.py re-checks the oracle against those
+fixtures on every run, so the oracle cannot drift from the reference unnoticed.
+
+The reference uses stock torch ops; using the same ops in the same order makes this
+restatement bit-identical to the reference on the same host (make_golden.py asserts
+exact equality), which is the property the token-exactness tests lean on.
+
+file:line citations are into /root/reference/drakes_dna/.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+MASK_INDEX = 4        # diffusion_gosai_update.py:82-88 (vocab 4 -> 5, mask is the last id)
+VOCAB = 5
+NEG_INFINITY = -1000000.0   # diffusion_gosai_update.py:127
+NOISE_EPS = 1e-3      # noise_schedule.py:134
+
+
+# --------------------------------------------------------------------------- schedule
+def total_noise(t):
+    """LogLinearNoise.total_noise — noise_schedule.py:143-144."""
+    return -torch.log1p(-(1 - NOISE_EPS) * t)
+
+
+def timestep_grid(num_steps, eps=1e-5):
+    """`timesteps`, `dt` of _sample — diffusion_gosai_update.py:521-523."""
+    return torch.linspace(1, eps, num_steps + 1), (1 - eps) / num_steps
+
+
+def step_scalars(num_steps, eps=1e-5):
+    """fp32 table [num_steps, 4] = (t, sigma_t, move_chance_t, move_chance_s).
+
+    Follows _ddpm_update — diffusion_gosai_update.py:463-474 — for one batch row
+    (all rows are equal: :527-528)."""
+    ts, dt = timestep_grid(num_steps, eps)
+    t = ts[:num_steps].reshape(-1, 1) * torch.ones(1, 1)
+    sigma_t = total_noise(t).squeeze(-1)
+    sigma_s = total_noise(t - dt).squeeze(-1)
+    mc_t = 1 - torch.exp(-sigma_t)
+    mc_s = 1 - torch.exp(-sigma_s)
+    return torch.stack([t.squeeze(-1), sigma_t, mc_t, mc_s], dim=1)
+
+
+# --------------------------------------------------------------------------- denoiser
+def n_layers_of(sd):
+    n = 0
+    while f'backbone.convs.{n}.weight' in sd:
+        n += 1
+    return n
+
+
+def layer_dilation(i, n_layers):
+    """convs = 5 layer types, each repeated num_cnn_stacks times consecutively —
+    models/dnaconv.py:53-58."""
+    return (1, 1, 4, 16, 64)[i // (n_layers // 5)]
+
+
+def time_embedding(sd, sigma):
+    """relu(Linear(GaussianFourierProjection(sigma))) — models/dnaconv.py:19-21,50,82."""
+    W = sd['backbone.time_embedder.0.W']
+    proj = sigma[:, None] * W[None, :] * 2 * np.pi
+    four = torch.cat([torch.sin(proj), torch.cos(proj)], dim=-1)
+    return F.relu(F.linear(four, sd['backbone.time_embedder.1.weight'],
+                           sd['backbone.time_embedder.1.bias']))
+
+
+def cnn_forward(sd, seq, sigma, return_feats=False):
+    """CNNModel.forward — models/dnaconv.py:74-110 (clean_data=False, no cfg, p_drop=0).
+
+    seq: int64 [B,L] or float [B,L,5]; sigma: [B].  Returns logits [B,L,5]."""
+    if not (seq.ndim > 2 and seq.shape[-1] == VOCAB):
+        seq = F.one_hot(seq, num_classes=VOCAB).float()
+    temb = time_embedding(sd, sigma)
+    feat = F.relu(F.conv1d(seq.permute(0, 2, 1), sd['backbone.linear.weight'],
+                           sd['backbone.linear.bias'], padding=4))
+    n = n_layers_of(sd)
+    feats = [feat]
+    for i in range(n):
+        d = layer_dilation(i, n)
+        tb = F.linear(temb, sd[f'backbone.time_layers.{i}.dense.weight'],
+                      sd[f'backbone.time_layers.{i}.dense.bias'])
+        h = feat + tb[:, :, None]
+        C = h.shape[1]
+        h = F.layer_norm(h.permute(0, 2, 1), (C,), sd[f'backbone.norms.{i}.weight'],
+                         sd[f'backbone.norms.{i}.bias'])
+        h = F.relu(F.conv1d(h.permute(0, 2, 1), sd[f'backbone.convs.{i}.weight'],
+                            sd[f'backbone.convs.{i}.bias'], dilation=d, padding=4 * d))
+        feat = h + feat
+        feats.append(feat)
+    y = F.relu(F.conv1d(feat, sd['backbone.final_conv.0.weight'], sd['backbone.final_conv.0.bias']))
+    y = F.conv1d(y, sd['backbone.final_conv.2.weight'], sd['backbone.final_conv.2.bias'])
+    logits = y.permute(0, 2, 1)
+    if return_feats:
+        return logits, feats
+    return logits
+
+
+# --------------------------------------------------------------------------- SUBS
+def subs_parameterization(logits, xt):
+    """_subs_parameterization — diffusion_gosai_update.py:243-253, without the in-place
+    writes: same values, and (as there) no gradient flows through unmasked rows."""
+    shift = torch.zeros(VOCAB, dtype=logits.dtype)
+    shift[MASK_INDEX] = NEG_INFINITY
+    logits = logits + shift
+    logp = logits - torch.logsumexp(logits, dim=-1, keepdim=True)
+    if xt.ndim > 2 and xt.shape[-1] == VOCAB:
+        xt = xt.argmax(dim=-1)
+    unmasked = (xt != MASK_INDEX)
+    held = torch.full_like(logp, NEG_INFINITY).scatter(-1, xt.unsqueeze(-1), 0.0)
+    return torch.where(unmasked.unsqueeze(-1), held, logp)
+
+
+def model_forward(sd, x, sigma, time_conditioning=False):
+    """Diffusion.forward + _process_sigma — diffusion_gosai_update.py:255-275."""
+    if sigma.ndim > 1:
+        sigma = sigma.squeeze(-1)
+    if not time_conditioning:
+        sigma = torch.zeros_like(sigma)
+    return subs_parameterization(cnn_forward(sd, x, sigma), x)
+
+
+# --------------------------------------------------------------------------- step
+def gumbel_norm(u):
+    """1e-10 - log(U + 1e-10) — diffusion_gosai_update.py:25-27."""
+    return 1e-10 - (u + 1e-10).log()
+
+
+def sample_categorical(q, u):
+    """_sample_categorical with the uniform draw injected — :24-28 (divide, then argmax)."""
+    return (q / gumbel_norm(u)).argmax(dim=-1)
+
+
+def sample_categorical_gradient(q, u, temp=1.0):
+    """_sample_categorical_gradient — :30-35."""
+    return F.softmax((torch.log(q) - torch.log(gumbel_norm(u))) / temp, 2)
+
+
+def posterior(log_p_x0, mc_t, mc_s):
+    """q_xs of _ddpm_update — :478-480.  mc_* broadcast as [B,1,1] or scalars."""
+    q = log_p_x0.exp() * (mc_t - mc_s)
+    mask_col = torch.zeros(VOCAB, dtype=torch.bool)
+    mask_col[MASK_INDEX] = True
+    return torch.where(mask_col, torch.as_tensor(mc_s, dtype=q.dtype).expand_as(q[..., :1]), q)
+
+
+def hard_step_from_logp(log_p_x0, x, u, mc_t, mc_s):
+    """Tail of _ddpm_update — :478-486."""
+    xs = sample_categorical(posterior(log_p_x0, mc_t, mc_s), u)
+    copy_flag = (x != MASK_INDEX).to(x.dtype)
+    return copy_flag * x + (1 - copy_flag) * xs
+
+
+def hard_step_from_logits(logits, x, u, mc_t, mc_s):
+    """SUBS + posterior + Gumbel-argmax + carry-over for raw backbone logits."""
+    return hard_step_from_logp(subs_parameterization(logits, x), x, u, mc_t, mc_s)
+
+
+def soft_step_from_logp(log_p_x0, x_soft, u, mc_t, mc_s, temp=1.0, copy_flag_temp=None):
+    """Tail of _ddpm_update_finetune_gradient — :572-586.  Returns (x_next, soft_copy_flag)."""
+    xs = sample_categorical_gradient(posterior(log_p_x0, mc_t, mc_s), u, temp)
+    if copy_flag_temp is not None:
+        flag = torch.sigmoid((1 - x_soft[:, :, MASK_INDEX].unsqueeze(-1)) / copy_flag_temp)
+    else:
+        flag = 1 - x_soft[:, :, MASK_INDEX].unsqueeze(-1)
+    return flag * x_soft + (1 - flag) * xs, flag
+
+
+class Schedule:
+    """Per-step tensors exactly as _sample/_ddpm_update build them (all rows equal)."""
+
+    def __init__(self, num_steps, eps=1e-5):
+        self.num_steps = num_steps
+        self.timesteps, self.dt = timestep_grid(num_steps, eps)
+
+    def at(self, i, batch):
+        t = self.timesteps[i] * torch.ones(batch, 1)
+        sigma_t = total_noise(t).squeeze(-1)
+        sigma_s = total_noise(t - self.dt).squeeze(-1)
+        mc_t = (1 - torch.exp(-sigma_t))[:, None, None]
+        mc_s = (1 - torch.exp(-sigma_s))[:, None, None]
+        return sigma_t, mc_t, mc_s
+
+
+# --------------------------------------------------------------------------- samplers
+def sample(sd, batch, length, num_steps, uniform_fn, eps=1e-5, time_conditioning=False,
+           noise_removal=True, trace=None):
+    """Diffusion._sample, ddpm predictor — diffusion_gosai_update.py:506-550.
+
+    uniform_fn(step, (B,L,5)) -> float32 tensor replaces torch.rand_like (:27)."""
+    with torch.no_grad():
+        x = MASK_INDEX * torch.ones(batch, length, dtype=torch.int64)          # :438-440
+        sch = Schedule(num_steps, eps)
+        for i in range(num_steps):
+            sigma_t, mc_t, mc_s = sch.at(i, batch)
+            logp = model_forward(sd, x, sigma_t, time_conditioning)
+            x = hard_step_from_logp(logp, x, uniform_fn(i, tuple(logp.shape)), mc_t, mc_s)
+            if trace is not None:
+                trace.append(x.clone())
+        if noise_removal:                                                      # :541-549
+            t = sch.timesteps[-1] * torch.ones(batch, 1)
+            logp = model_forward(sd, x, total_noise(t), time_conditioning)
+            x = logp[:, :, :-1].argmax(dim=-1)
+        return x
+
+
+def sample_finetune_gradient(sd, batch, length, num_steps, truncate_steps, uniform_fn,
+                             eps=1e-5, temp=1.0, copy_flag_temp=None, time_conditioning=False):
+    """Diffusion._sample_finetune_gradient — diffusion_gosai_update.py:589-630.
+
+    Gradients flow to whichever tensors of `sd` have requires_grad=True."""
+    x = MASK_INDEX * torch.ones(batch, length, dtype=torch.int64)
+    sch = Schedule(num_steps, eps)
+    last_x_list, condt_list, mct_list, flag_list = [], [], [], []
+    for i in range(num_steps):
+        sigma_t, mc_t, mc_s = sch.at(i, batch)
+        if i < num_steps - truncate_steps:                                     # :615-619
+            logp = model_forward(sd, x, sigma_t, time_conditioning)
+            u = uniform_fn(i, tuple(logp.shape))
+            last_x = F.one_hot(x, num_classes=VOCAB).to(torch.float32).detach()
+            copy_flag = (x != MASK_INDEX).to(x.dtype).unsqueeze(-1)
+            x = hard_step_from_logp(logp, x, u, mc_t, mc_s).detach()
+        else:                                                                  # :621, :552-586
+            if x.ndim == 2:
+                x = F.one_hot(x, num_classes=VOCAB).to(torch.float32)
+            logp = model_forward(sd, x, sigma_t, time_conditioning)
+            u = uniform_fn(i, tuple(logp.shape))
+            last_x = x
+            x, copy_flag = soft_step_from_logp(logp, x, u, mc_t, mc_s, temp, copy_flag_temp)
+        last_x_list.append(last_x)
+        condt_list.append(sigma_t)
+        mct_list.append(mc_t)
+        flag_list.append(copy_flag)
+    if x.ndim == 2:  # truncate_steps == 0: the reference would fail at :628; keep its precondition
+        raise ValueError('truncate_steps must be >= 1')
+    hard = F.one_hot(x[:, :, :-1].argmax(dim=-1), num_classes=VOCAB - 1).to(torch.float32)
+    out = x[:, :, :-1] + (hard - x[:, :, :-1]).detach()                        # :628-630
+    return out, last_x_list, condt_list, mct_list, flag_list
+
+
+def kl_step(logp_new, logp_old, last_x, copy_flag, mc_t_scalar):
+    """Per-step KL term of fine_tune — finetune_reward_bp.py:67-74.  Inputs are full
+    5-wide log-probs; returns [B]."""
+    lp, lo = logp_new[:, :, :-1], logp_old[:, :, :-1]
+    p, po = lp.exp(), lo.exp()
+    kl = copy_flag * (-p + po + p * (lp - lo)) / mc_t_scalar
+    return (kl * last_x[:, :, :-1]).sum((1, 2))

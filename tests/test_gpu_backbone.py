@@ -1,0 +1,79 @@
+"""fp32 denoiser kernels against the reference's golden logits and the oracle.
+
+Tolerance (stated per SURVEY 8d): the kernels accumulate each 1152-term convolution dot product
+as one fp32 fma chain while the reference's CPU conv uses a blocked order; over 20 residual
+layers the logits (|logit| ~ 1) agree to a few 1e-5.  We assert 2e-4 absolute, 1e-4 relative."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import drakes_oracle as O
+
+pytestmark = pytest.mark.gpu
+ATOL, RTOL = 2e-4, 1e-4
+
+
+def test_time_embedding(gpu_model, dev, det_sd):
+    g = load_golden('f2_backbone.npz')
+    sigma = torch.from_numpy(g['sigma']).to(dev)
+    from drakes_amd import ops
+    pk = gpu_model.backbone.packed()
+    temb = ops.time_embed_fwd(sigma, pk['four_W'], pk['temb_w'], pk['temb_b']).cpu().numpy()
+    # sin/cos of arguments up to ~4e3 rad: identical fp32 argument on both sides, results differ by ulps
+    np.testing.assert_allclose(temb, g['time_emb'], rtol=1e-5, atol=2e-5)
+
+
+def test_logits_golden(gpu_model, dev):
+    g = load_golden('f2_backbone.npz')
+    x = torch.from_numpy(g['x_int']).to(dev)
+    soft = torch.from_numpy(g['soft']).to(dev)
+    z = torch.zeros(4, device=dev)
+    with torch.no_grad():
+        got_int = gpu_model.backbone(x, z).cpu().numpy()
+        got_soft = gpu_model.backbone(soft, z).cpu().numpy()
+    np.testing.assert_allclose(got_int, g['logits_int'], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(got_soft, g['logits_soft'], rtol=RTOL, atol=ATOL)
+    print('max |dlogit| int/soft:', np.abs(got_int - g['logits_int']).max(), np.abs(got_soft - g['logits_soft']).max())
+
+
+def test_logits_golden_time_conditioned(gpu_model, dev):
+    g = load_golden('f2_backbone.npz')
+    x = torch.from_numpy(g['x_int']).to(dev)
+    soft = torch.from_numpy(g['soft']).to(dev)
+    sigma = torch.from_numpy(g['sigma']).to(dev)
+    with torch.no_grad():
+        np.testing.assert_allclose(gpu_model.backbone(x, sigma).cpu().numpy(), g['logits_int_tc'], rtol=RTOL, atol=ATOL)
+        np.testing.assert_allclose(gpu_model.backbone(soft, sigma).cpu().numpy(), g['logits_soft_tc'], rtol=RTOL,
+                                   atol=ATOL)
+
+
+def test_forward_logp_golden(gpu_model, dev):
+    g = load_golden('f2_backbone.npz')
+    x = torch.from_numpy(g['x_int']).to(dev)
+    soft = torch.from_numpy(g['soft']).to(dev)
+    sigma = torch.from_numpy(g['sigma']).to(dev)[:, None]
+    with torch.no_grad():
+        lp = gpu_model.forward(x, sigma).cpu().numpy()
+        lps = gpu_model.forward(soft, sigma).cpu().numpy()
+    np.testing.assert_allclose(lp, g['logp_int'], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(lps, g['logp_soft'], rtol=RTOL, atol=ATOL)
+    try:
+        gpu_model.time_conditioning = True
+        with torch.no_grad():
+            lptc = gpu_model.forward(x, sigma).cpu().numpy()
+    finally:
+        gpu_model.time_conditioning = False
+    np.testing.assert_allclose(lptc, g['logp_int_tc'], rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize('B,L', [(1, 9), (3, 65), (2, 333), (1, 1024)])
+def test_logits_vs_oracle_ragged_shapes(gpu_model, dev, det_sd, B, L):
+    """Lengths that are not multiples of the 64-row tile, shorter than the dilation reach,
+    and the 1024-bp stress length."""
+    gen = np.random.Generator(np.random.PCG64(L))
+    x = torch.from_numpy(gen.integers(0, 5, (B, L)))
+    with torch.no_grad():
+        want = O.cnn_forward(det_sd, x, torch.zeros(B)).numpy()
+        got = gpu_model.backbone(x.to(dev), torch.zeros(B, device=dev)).cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=RTOL, atol=ATOL)

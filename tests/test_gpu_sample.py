@@ -1,0 +1,69 @@
+"""End-to-end `_sample` on the GPU against tokens captured from the reference.
+
+At the step boundary tokens are bit-exact (test_gpu_step.py).  End to end the fp32 logits differ
+from the CPU reference in the last bits (different accumulation order), and argmax(q/g) can flip
+on a near-tie; a flipped token then changes every later forward.  We therefore report the
+mismatch rate and require it to be tiny (0 expected on these fixtures)."""
+import numpy as np
+import pytest
+import torch
+
+import drakes_amd
+from conftest import load_golden
+from drakes_amd import ops
+
+pytestmark = pytest.mark.gpu
+
+
+def test_sample_short_golden(dev, det_sd):
+    g = load_golden('f4_sample_short.npz')
+    m = drakes_amd.Diffusion(drakes_amd.default_config(length=64, steps=16)).to(dev)
+    m.load_state_dict(det_sd)
+    toks = m._sample(eval_sp_size=5, seed=int(g['useed'])).cpu()
+    assert toks.dtype == torch.int64 and toks.shape == (5, 64)
+    rate = (toks != torch.from_numpy(g['tokens'])).float().mean().item()
+    print('mismatch rate short:', rate)
+    assert rate == 0.0
+
+
+def test_sample_full_golden(gpu_model, dev):
+    g = load_golden('f4_sample.npz')
+    seed = int(g['useed'])
+    toks = gpu_model._sample(eval_sp_size=8, seed=seed).cpu()
+    want = torch.from_numpy(g['tokens'])
+    rate = (toks != want).float().mean().item()
+    rows = (toks != want).any(1).sum().item()
+    print(f'mismatch rate full: {rate} ({rows}/8 sequences touched)')
+    assert toks.min() >= 0 and toks.max() <= 3
+    assert rate <= 0.02, rate
+    # injected uniforms give the same tokens as the in-kernel generator
+    toks2 = gpu_model._sample(eval_sp_size=8, seed=123,
+                              uniforms=lambda i: ops.step_uniforms(8, 200, seed, i, 0, device=dev)).cpu()
+    assert torch.equal(toks, toks2)
+
+
+def test_sample_time_conditioned_golden(dev, det_sd):
+    g = load_golden('f4_sample_tc.npz')
+    m = drakes_amd.Diffusion(drakes_amd.default_config(time_conditioning=True)).to(dev)
+    m.load_state_dict(det_sd)
+    toks = m._sample(eval_sp_size=4, seed=int(g['useed'])).cpu()
+    rate = (toks != torch.from_numpy(g['tokens'])).float().mean().item()
+    print('mismatch rate tc:', rate)
+    assert rate <= 0.02, rate
+
+
+def test_sample_shard_invariance(gpu_model):
+    """Rows draw the noise of their GLOBAL index: a shard with sample_offset reproduces the rows
+    of the full batch."""
+    full = gpu_model._sample(eval_sp_size=6, seed=77, num_steps=8)
+    part = gpu_model._sample(eval_sp_size=3, seed=77, num_steps=8, sample_offset=3)
+    assert torch.equal(full[3:], part)
+
+
+def test_sample_reproducible_under_manual_seed(gpu_model):
+    torch.manual_seed(5)
+    a = gpu_model._sample(eval_sp_size=2, num_steps=4)
+    torch.manual_seed(5)
+    b = gpu_model._sample(eval_sp_size=2, num_steps=4)
+    assert torch.equal(a, b)
+    assert gpu_model._sample(eval_sp_size=0, num_steps=4).shape == (0, 200)
