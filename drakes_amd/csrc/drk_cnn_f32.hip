@@ -242,6 +242,7 @@ extern "C" int drk_time_bias_fwd(const float* temb, int nb, const float* dense_w
 
 extern "C" int drk_stem_fwd(const int64_t* x, const float* x_soft, const float* w_t, const float* bias, float* feat,
                             int B, int L, void* stream) {
+  DRK_SHAPE_GUARD("drk_stem_fwd");
   ARGCHECK((x || x_soft) && w_t && bias && feat && B >= 0 && L > 0, "drk_stem_fwd");
   const long M = (long)B * L;
   if (M == 0) return DRK_OK;
@@ -253,6 +254,7 @@ extern "C" int drk_stem_fwd(const int64_t* x, const float* x_soft, const float* 
 
 extern "C" int drk_ln_fwd(const float* feat, const float* tbias, long tbias_bstride, const float* gamma,
                           const float* beta, float* h, float* mean, float* rstd, int B, int L, void* stream) {
+  DRK_SHAPE_GUARD("drk_ln_fwd");
   ARGCHECK(feat && gamma && beta && h && B >= 0 && L > 0 && (!mean == !rstd), "drk_ln_fwd");
   const long M = (long)B * L;
   if (M == 0) return DRK_OK;
@@ -264,6 +266,7 @@ extern "C" int drk_ln_fwd(const float* feat, const float* tbias, long tbias_bstr
 
 extern "C" int drk_conv_fwd_f32(const float* h, const float* w_pk, const float* bias, const float* resid, float* out,
                                 int B, int L, int taps, int dilation, int relu, void* stream) {
+  DRK_SHAPE_GUARD("drk_conv_fwd_f32");
   ARGCHECK(h && w_pk && bias && out && B >= 0 && L > 0 && taps >= 1 && (taps & 1) && dilation >= 0,
            "drk_conv_fwd_f32");
   const long M = (long)B * L;
@@ -276,6 +279,7 @@ extern "C" int drk_conv_fwd_f32(const float* h, const float* w_pk, const float* 
 
 extern "C" int drk_head_out_fwd(const float* y, const float* w, const float* bias, float* logits, int B, int L,
                                 void* stream) {
+  DRK_SHAPE_GUARD("drk_head_out_fwd");
   ARGCHECK(y && w && bias && logits && B >= 0 && L > 0, "drk_head_out_fwd");
   const long M = (long)B * L;
   if (M == 0) return DRK_OK;

@@ -93,5 +93,11 @@ __device__ __forceinline__ int drk_gumbel_argmax(const float q[DRK_V], const flo
     if (e__ != hipSuccess) return drk_set_error(e__, __func__); \
   } while (0)
 
+// Shape guard of every entry point: a negative batch or empty length is an error, an EMPTY batch
+// is a successful no-op (its pointers may be null), checked before the pointers are.
+#define DRK_SHAPE_GUARD(name)                                                        \
+  if (B < 0 || L <= 0) return drk_set_error_msg(DRK_EINVAL, name ": bad shape");     \
+  if (B == 0) return DRK_OK
+
 int drk_set_error(hipError_t e, const char* where);
 int drk_set_error_msg(int code, const char* msg);

@@ -114,6 +114,7 @@ static inline int grid_for(long n) {
 
 extern "C" int drk_step_uniforms(float* u, int B, int L, uint64_t seed, uint32_t step, uint64_t sample_offset,
                                  void* stream) {
+  DRK_SHAPE_GUARD("drk_step_uniforms");
   if (!u || B < 0 || L <= 0) return drk_set_error_msg(DRK_EINVAL, "drk_step_uniforms: bad arguments");
   const long n = (long)B * L;
   if (n == 0) return DRK_OK;
@@ -125,6 +126,7 @@ extern "C" int drk_step_uniforms(float* u, int B, int L, uint64_t seed, uint32_t
 
 extern "C" int drk_subs_fwd(const float* logits, const int64_t* x, const float* x_soft, float* logp, int B, int L,
                             void* stream) {
+  DRK_SHAPE_GUARD("drk_subs_fwd");
   if (!logits || !logp || (!x && !x_soft) || B < 0 || L <= 0)
     return drk_set_error_msg(DRK_EINVAL, "drk_subs_fwd: bad arguments");
   const long n = (long)B * L;
@@ -137,6 +139,7 @@ extern "C" int drk_subs_fwd(const float* logits, const int64_t* x, const float* 
 extern "C" int drk_reverse_step_hard(const float* logits, const int64_t* x, const float* uniforms, int64_t* x_next,
                                      int B, int L, float mc_t, float mc_s, uint64_t seed, uint32_t step,
                                      uint64_t sample_offset, void* stream) {
+  DRK_SHAPE_GUARD("drk_reverse_step_hard");
   if (!logits || !x || !x_next || B < 0 || L <= 0)
     return drk_set_error_msg(DRK_EINVAL, "drk_reverse_step_hard: bad arguments");
   const long n = (long)B * L;
@@ -152,6 +155,7 @@ extern "C" int drk_reverse_step_hard(const float* logits, const int64_t* x, cons
 }
 
 extern "C" int drk_denoise_argmax(const float* logits, const int64_t* x, int64_t* x_out, int B, int L, void* stream) {
+  DRK_SHAPE_GUARD("drk_denoise_argmax");
   if (!logits || !x || !x_out || B < 0 || L <= 0)
     return drk_set_error_msg(DRK_EINVAL, "drk_denoise_argmax: bad arguments");
   const long n = (long)B * L;

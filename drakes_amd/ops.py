@@ -15,6 +15,51 @@ V = 5        # vocabulary incl. mask
 MASK = 4
 
 
+class _Profile:
+    """HIP-event timing of the dominant kernel's launches, on the stream they are launched on
+    (torch's current stream).  Off by default; bench.py switches it on over its timed region."""
+
+    def __init__(self):
+        self.on = False
+        self._pairs = []
+        self._n = 0
+        self.every = 1
+        self.name = None
+
+    def enable(self, every=1):
+        self.on, self.every, self._pairs, self._n, self.name = True, max(1, every), [], 0, None
+
+    def bracket(self, name, flop, launch):
+        """Runs launch(); when profiling, every `every`-th call is bracketed by an event pair."""
+        if not self.on:
+            return launch()
+        self._n += 1
+        if self._n % self.every:
+            return launch()
+        self.name = name
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        r = launch()
+        b.record()
+        self._pairs.append((a, b, flop))
+        return r
+
+    def disable(self):
+        """-> (kernel name, launches timed, average ms per launch, flop per launch)."""
+        self.on = False
+        torch.cuda.synchronize()
+        n = len(self._pairs)
+        if n == 0:
+            return (None, 0, None, 0)
+        ms = sum(a.elapsed_time(b) for a, b, _ in self._pairs)
+        fl = sum(f for _, _, f in self._pairs)
+        self._pairs = []
+        return (self.name, n, ms / n, fl / n)
+
+
+PROFILE = _Profile()
+
+
 def _dev_ptr(t, dtype, name):
     if t is None:
         return None
@@ -113,8 +158,12 @@ def conv_fwd_f32(h, w_pk, bias, resid, dilation, relu=True, out=None):
     B, L, _ = h.shape
     taps = w_pk.shape[0]
     out = out if out is not None else torch.empty_like(h)
-    _lib.call('drk_conv_fwd_f32', _f(h, 'h'), _f(w_pk, 'w_pk'), _f(bias, 'bias'), _f(resid, 'resid'), _f(out, 'out'),
-              B, L, taps, dilation, 1 if relu else 0, _stream())
+    args = (_f(h, 'h'), _f(w_pk, 'w_pk'), _f(bias, 'bias'), _f(resid, 'resid'), _f(out, 'out'), B, L, taps, dilation,
+            1 if relu else 0, _stream())
+    if taps == 9:
+        PROFILE.bracket('k_conv_f32<2>', 2.0 * B * L * C * C * taps, lambda: _lib.call('drk_conv_fwd_f32', *args))
+    else:
+        _lib.call('drk_conv_fwd_f32', *args)
     return out
 
 
