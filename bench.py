@@ -36,7 +36,7 @@ FLOP_PER_POS_FWD = 11520 + 20 * FLOP_PER_POS_LAYER + 34048   # 5.944 MFLOP
 PEAK = {'bf16': 2500.0, 'fp32': 157.3}            # TFLOP/s dense MFMA, MI355X_MICROARCH.md
 
 
-def cpu_baseline(seconds_budget=25.0):
+def cpu_baseline(seconds_budget=15.0):
     """The CPU oracle (a restatement pinned bit-for-bit to the reference, oracle/make_golden.py)
     on the host cores: same 128-step schedule, a bounded batch."""
     from drakes_amd.det_init import det_state_dict
@@ -48,7 +48,10 @@ def cpu_baseline(seconds_budget=25.0):
     t0 = time.perf_counter()
     O.sample(sd, 2, L, 4, uni)                      # warm-up / first-touch
     warm = time.perf_counter() - t0
-    B = 16
+    t0 = time.perf_counter()
+    O.sample(sd, 16, L, NUM_STEPS, uni)             # sizing run: how many sequences fit the budget
+    probe = time.perf_counter() - t0
+    B = int(max(16, min(512, 16 * seconds_budget / max(probe, 1e-3)))) // 16 * 16
     t0 = time.perf_counter()
     O.sample(sd, B, L, NUM_STEPS, uni)
     dt = time.perf_counter() - t0
