@@ -65,7 +65,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--dtype', default='fp32', choices=['bf16', 'fp32'])
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--batch', type=int, default=1024, help='sequences per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()

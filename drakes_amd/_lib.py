@@ -25,6 +25,8 @@ SIGNATURES = {
     'drk_ln_fwd': [_P, _P, c_long, _P, _P, _P, _P, _P, c_int, c_int, _P],
     'drk_conv_fwd_f32': [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P],
     'drk_head_out_fwd': [_P, _P, _P, _P, c_int, c_int, _P],
+    'drk_sample_bf16': [_P, _P, _P, c_long, _P, _P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, c_int,
+                        c_uint64, c_uint64, _P],
 }
 
 _lib = None

@@ -19,6 +19,7 @@ LIB = os.path.join(HERE, 'libdrakes_hip.so')
 SOURCES = {
     'drk_step.hip': ['-ffp-contract=off'],
     'drk_cnn_f32.hip': ['-ffp-contract=off'],
+    'drk_sample_bf16.hip': ['-ffp-contract=off'],
 }
 COMMON = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function']
 

@@ -1,0 +1,445 @@
+// drk_sample_bf16 — the whole reverse-sampling loop of Diffusion._sample
+// (diffusion_gosai_update.py:506-550) as ONE persistent launch on gfx950.
+//
+// One workgroup (8 waves, two per SIMD) owns one sequence for all num_steps+1 denoiser
+// forwards; sequences never interact, so there is no inter-workgroup traffic.
+//   * the fp32 residual stream lives in REGISTERS, in the MFMA accumulator layout, for the
+//     whole forward; it never touches LDS or HBM;
+//   * the LayerNorm output h (bf16) lives in LDS, XOR-swizzled [position][128 ch], and is the
+//     B operand of every tap of the dilated convolution: a tap is a row offset into that
+//     image (rows outside [0,L) are redirected to one all-zero row = 'same' zero padding);
+//   * weights (bf16, 5.9 MB for the whole network) stream L2 -> LDS with global_load_lds in
+//     32 KB stages, double-buffered, one stage per tap, pre-swizzled in global memory so the
+//     copy is linear; every CU streams the same bytes at about the same time, so the stream is
+//     L2-resident;
+//   * the MFMA is v_mfma_f32_32x32x16_bf16 with A = weights [32 co][16 ci] and
+//     B = activations [16 ci][32 positions]: the accumulator then holds, per lane, ONE position
+//     and 16 channels, which makes the LayerNorm reduction a local sum plus one cross-half
+//     exchange plus four partials through LDS, and the h write-back four 8-byte stores;
+//   * stem (one-hot x 45 weights), final_conv.0/.2, SUBS, posterior, Philox, Gumbel-argmax and
+//     carry-over are fused in; per step only the tokens change, and they stay in LDS.
+// HBM traffic per sequence per step: ~0 (tokens out once at the end).  MFMA-bound.
+//
+// Work split: output tile = 32 channels x 32 positions; 4 channel tiles x 7 position tiles = 28
+// tiles per k-step.  Wave w owns channel tile (w & 3) and position tiles (w >> 2) + 2t: waves
+// 0-3 take 4 tiles, waves 4-7 take 3, and waves w, w+4 share a SIMD -> 7 tiles per SIMD.
+#include "drk_common.h"
+#include "../../include/drakes_hip.h"
+
+typedef __bf16 bf16v8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16v4 __attribute__((ext_vector_type(4)));
+
+#define ROWB 256                 // bytes per LDS image row (128 bf16)
+#define MAXPOS 224               // 7 position tiles
+#define ZROW 224                 // the all-zero row of the h image
+#define STAGE_BYTES 32768        // one weight stage: [128 rows][128 cols] bf16
+#define OFF_HB 0
+#define OFF_WB0 (OFF_HB + (ZROW + 1) * ROWB)        // 57600
+#define OFF_WB1 (OFF_WB0 + STAGE_BYTES)
+#define OFF_PART (OFF_WB1 + STAGE_BYTES)            // float2 [4][224]
+#define OFF_LOG (OFF_PART + 4 * MAXPOS * 8)         // float [224][8]
+#define OFF_TOK (OFF_LOG + MAXPOS * 8 * 4)          // int [224]
+#define LDS_BYTES (OFF_TOK + MAXPOS * 4)            // 138368
+
+struct SampleArgs {
+  const char* wstream;      // stages, bf16, pre-swizzled: stem, n_layers*9 taps, head0, head2
+  const float* vecs;        // [2 + 3*n_layers + 1][128]: stem bias; per layer gamma,beta,conv bias; head0 bias; head2 bias
+  const float* tbias;       // [n_tb][n_layers][128]
+  long tb_fwd_stride;       // floats between consecutive forwards' rows (0: one row for all)
+  const float* mc_table;    // [num_steps][2] = (move_chance_t, move_chance_s)
+  const float* uniforms;    // optional [num_steps][B][L][5]
+  const int64_t* x_init;    // optional [B][L]; else all-mask prior
+  int64_t* x_out;           // [B][L]
+  float* logits_out;        // optional [B][L][5]: raw logits of forward `dump_fwd`
+  int dump_fwd;
+  float* dbg_feat;          // optional [B][L][128]: residual stream of forward dump_fwd after layer dbg_layer (-1: stem)
+  int dbg_layer;
+  int B, L, num_steps, n_layers, noise_removal;
+  unsigned long long dilpk[4];   // 8 bits per layer
+  uint64_t seed, sample_offset;
+};
+
+// ---- stage streaming -----------------------------------------------------------------------
+__device__ __forceinline__ void prefetch_stage(const char* __restrict__ src, char* smem, int dst_off, int tid, int wave) {
+#pragma unroll
+  for (int it = 0; it < STAGE_BYTES / (512 * 16); ++it) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (it * 512 + tid) * 16),
+                                     (__attribute__((address_space(3))) void*)(smem + dst_off + it * 8192 + wave * 1024),
+                                     16, 0, 0);
+  }
+}
+
+__device__ __forceinline__ void stage_sync() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+}
+
+// ---- one weight stage (= one tap, or a 1x1 conv) --------------------------------------------
+// acc[t] += W_stage[co tile] . h[rows of tile t shifted by `off`], K = 16*KS channels.
+template <int KS>
+__device__ __forceinline__ void mma_stage(const char* smem, int wb_off, int off, int L, int lr, int half, int ct,
+                                          int grp, int nt, f32x16 (&acc)[4]) {
+  const int arow = 32 * ct + lr;
+  const char* abase = smem + wb_off + arow * ROWB;
+  const int am = (half ^ (arow & 15)) << 4;
+  const char* bbase[4];
+  int bm[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int pp = 32 * (grp + 2 * t) + lr + off;
+    const int row = ((unsigned)pp < (unsigned)L) ? pp : ZROW;
+    bbase[t] = smem + OFF_HB + row * ROWB;
+    bm[t] = (half ^ (row & 15)) << 4;
+  }
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const bf16v8 a = *(const bf16v8*)(abase + ((32 * ks) ^ am));
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      if (t < nt) {
+        const bf16v8 b = *(const bf16v8*)(bbase[t] + ((32 * ks) ^ bm[t]));
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t], 0, 0, 0);
+      }
+    }
+  }
+}
+
+// 16 per-channel values of this lane: channels 32ct + 8g + 4half + e  <->  register 4g + e.
+__device__ __forceinline__ void load_vec16(const float* __restrict__ v, int ct, int half, float (&o)[16]) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const f32x4 q = *(const f32x4*)(v + 32 * ct + 8 * g + 4 * half);
+    o[4 * g + 0] = q[0]; o[4 * g + 1] = q[1]; o[4 * g + 2] = q[2]; o[4 * g + 3] = q[3];
+  }
+}
+
+// Writes 16 channel values of position p as bf16 into the swizzled h image.
+__device__ __forceinline__ void store_h16(char* smem, int p, int ct, int half, const float (&x)[16]) {
+  char* row = smem + OFF_HB + p * ROWB + 8 * half;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    bf16v4 pk;
+    pk[0] = (__bf16)x[4 * g + 0]; pk[1] = (__bf16)x[4 * g + 1];
+    pk[2] = (__bf16)x[4 * g + 2]; pk[3] = (__bf16)x[4 * g + 3];
+    *(bf16v4*)(row + (((4 * ct + g) ^ (p & 15)) << 4)) = pk;
+  }
+}
+
+// LayerNorm of (feat + tbias) over the 128 channels of each position -> h image (bf16).
+// Two barriers inside: partial sums out, h visible.
+__device__ __forceinline__ void layernorm_to_h(char* smem, const f32x16 (&feat)[4], const float* __restrict__ tb,
+                                               const float* __restrict__ gamma, const float* __restrict__ beta, int L,
+                                               int lr, int half, int ct, int grp, int nt) {
+  float tbv[16];
+  load_vec16(tb, ct, half, tbv);
+  float2* part = (float2*)(smem + OFF_PART);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    if (t < nt) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float x = feat[t][i] + tbv[i];
+        s1 += x;
+        s2 += x * x;
+      }
+      s1 += __shfl_xor(s1, 32);
+      s2 += __shfl_xor(s2, 32);
+      if (half == 0) part[ct * MAXPOS + 32 * (grp + 2 * t) + lr] = make_float2(s1, s2);
+    }
+  }
+  __syncthreads();   // also: every wave is past its last read of the previous h image
+  float gv[16], bv[16];
+  load_vec16(gamma, ct, half, gv);
+  load_vec16(beta, ct, half, bv);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    if (t < nt) {
+      const int p = 32 * (grp + 2 * t) + lr;
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float2 q = part[c * MAXPOS + p];
+        s1 += q.x;
+        s2 += q.y;
+      }
+      const float mean = s1 * (1.0f / 128.0f);
+      const float var = fmaxf(s2 * (1.0f / 128.0f) - mean * mean, 0.0f);
+      const float rstd = 1.0f / sqrtf(var + 1e-5f);
+      float hv[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) hv[i] = (feat[t][i] + tbv[i] - mean) * rstd * gv[i] + bv[i];
+      if (p < L) store_h16(smem, p, ct, half, hv);
+    }
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ void dump_feat(float* __restrict__ dst, long b, int L, const f32x16 (&feat)[4], int lr, int half,
+                                          int ct, int grp, int nt) {
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    if (t < nt) {
+      const int p = 32 * (grp + 2 * t) + lr;
+      if (p < L) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 q = {feat[t][4 * g], feat[t][4 * g + 1], feat[t][4 * g + 2], feat[t][4 * g + 3]};
+          *(f32x4*)(dst + (b * L + p) * 128 + 32 * ct + 8 * g + 4 * half) = q;
+        }
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(512, 2) k_sample_bf16(const SampleArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int lr = lane & 31, half = lane >> 5;
+  const int ct = wave & 3, grp = wave >> 2;
+  const int L = a.L;
+  const int ntiles = (L + 31) >> 5;
+  int nt = 0;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) nt += (grp + 2 * t < ntiles) ? 1 : 0;
+  const int n_stages = 1 + 9 * a.n_layers + 2;
+  const long b = blockIdx.x;
+  const uint64_t sample = a.sample_offset + (uint64_t)b;
+  int* tok = (int*)(smem + OFF_TOK);
+  float* logit = (float*)(smem + OFF_LOG);
+
+  // ---- init: tokens, zero row, first stage -------------------------------------------------
+  for (int i = tid; i < MAXPOS; i += 512) tok[i] = (i < L) ? (a.x_init ? (int)a.x_init[b * L + i] : DRK_MASK) : DRK_MASK;
+  if (tid < ROWB / 4) ((int*)(smem + OFF_HB + ZROW * ROWB))[tid] = 0;
+  int stage = 0;      // index into the weight stream (wraps at n_stages)
+  int cur = 0;        // which LDS weight buffer holds `stage`
+  prefetch_stage(a.wstream, smem, OFF_WB0, tid, wave);
+  stage_sync();
+
+#define WB(c) ((c) ? OFF_WB1 : OFF_WB0)
+#define NEXT_STAGE()                                                                              \
+  do {                                                                                            \
+    const int nxt = (stage + 1 == n_stages) ? 0 : stage + 1;                                      \
+    prefetch_stage(a.wstream + (long)nxt * STAGE_BYTES, smem, WB(cur ^ 1), tid, wave);            \
+  } while (0)
+#define END_STAGE()                                   \
+  do {                                                \
+    stage_sync();                                     \
+    stage = (stage + 1 == n_stages) ? 0 : stage + 1;  \
+    cur ^= 1;                                         \
+  } while (0)
+
+  const int n_fwd = a.num_steps + (a.noise_removal ? 1 : 0);
+  for (int f = 0; f < n_fwd; ++f) {
+    const float* tb = a.tbias + (long)f * a.tb_fwd_stride;
+    f32x16 feat[4], acc[4];
+
+    // ---- stem: one-hot(x) [45 -> 48 of K] x W_stem, as 3 MFMA k-steps -----------------------
+    NEXT_STAGE();
+    {
+      const int arow = 32 * ct + lr;
+      const char* abase = smem + WB(cur) + arow * ROWB;
+      const int am = (half ^ (arow & 15)) << 4;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+        if (t < nt) {
+          const int p = 32 * (grp + 2 * t) + lr;
+          int nb[9];
+#pragma unroll
+          for (int k = 0; k < 9; ++k) {
+            const int q = p + k - 4;
+            nb[k] = ((unsigned)q < (unsigned)L) ? tok[q] : 7;
+          }
+#pragma unroll
+          for (int ks = 0; ks < 3; ++ks) {
+            const bf16v8 av = *(const bf16v8*)(abase + ((32 * ks) ^ am));
+            bf16v8 bv;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              // k = 16ks + 8half + j = 5*tap + v
+              const int k0 = 16 * ks + j, k1 = k0 + 8;
+              const int t0 = k0 / 5, v0 = k0 % 5, t1 = k1 / 5, v1 = k1 % 5;
+              const bool hit0 = (k0 < 45) && (nb[t0 < 9 ? t0 : 0] == v0);
+              const bool hit1 = (k1 < 45) && (nb[t1 < 9 ? t1 : 0] == v1);
+              bv[j] = (__bf16)((half ? hit1 : hit0) ? 1.0f : 0.0f);
+            }
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[t], 0, 0, 0);
+          }
+        }
+      }
+    }
+    {
+      float sb[16];
+      load_vec16(a.vecs, ct, half, sb);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) feat[t][i] = fmaxf(acc[t][i] + sb[i], 0.f);
+    }
+    END_STAGE();
+    if (a.dbg_feat && f == a.dump_fwd && a.dbg_layer == -1) dump_feat(a.dbg_feat, b, L, feat, lr, half, ct, grp, nt);
+    layernorm_to_h(smem, feat, tb, a.vecs + 128 * 1, a.vecs + 128 * 2, L, lr, half, ct, grp, nt);
+
+    // ---- 20 x (dilated conv + ReLU + residual, then the next layer's LayerNorm) -------------
+    for (int layer = 0; layer < a.n_layers; ++layer) {
+      const int dil = (int)((a.dilpk[layer >> 3] >> (8 * (layer & 7))) & 255ull);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+      for (int tap = 0; tap < 9; ++tap) {
+        NEXT_STAGE();
+        mma_stage<8>(smem, WB(cur), (tap - 4) * dil, L, lr, half, ct, grp, nt, acc);
+        END_STAGE();
+      }
+      {
+        float cb[16];
+        load_vec16(a.vecs + 128 * (1 + 3 * layer + 2), ct, half, cb);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) feat[t][i] += fmaxf(acc[t][i] + cb[i], 0.f);
+      }
+      if (a.dbg_feat && f == a.dump_fwd && a.dbg_layer == layer) dump_feat(a.dbg_feat, b, L, feat, lr, half, ct, grp, nt);
+      if (layer + 1 < a.n_layers) {
+        layernorm_to_h(smem, feat, tb + 128 * (layer + 1), a.vecs + 128 * (1 + 3 * (layer + 1)),
+                       a.vecs + 128 * (1 + 3 * (layer + 1) + 1), L, lr, half, ct, grp, nt);
+      }
+    }
+
+    // ---- head: final_conv.0 (1x1) + ReLU, final_conv.2 (128 -> 5) ---------------------------
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      if (t < nt) {
+        const int p = 32 * (grp + 2 * t) + lr;
+        float hv[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) hv[i] = feat[t][i];
+        if (p < L) store_h16(smem, p, ct, half, hv);
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+    }
+    __syncthreads();
+    NEXT_STAGE();
+    mma_stage<8>(smem, WB(cur), 0, L, lr, half, ct, grp, nt, acc);
+    END_STAGE();   // all reads of the feat image are done
+    {
+      float hb0[16];
+      load_vec16(a.vecs + 128 * (1 + 3 * a.n_layers), ct, half, hb0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (t < nt) {
+          const int p = 32 * (grp + 2 * t) + lr;
+          float hv[16];
+#pragma unroll
+          for (int i = 0; i < 16; ++i) hv[i] = fmaxf(acc[t][i] + hb0[i], 0.f);
+          if (p < L) store_h16(smem, p, ct, half, hv);
+        }
+      }
+    }
+    __syncthreads();
+    NEXT_STAGE();
+    {
+      // 5 output rows live in channel tile 0; position tile = wave (waves 0..6)
+      f32x16 lg;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) lg[i] = 0.f;
+      if (wave < ntiles) {
+        const char* abase = smem + WB(cur) + lr * ROWB;
+        const int am = (half ^ (lr & 15)) << 4;
+        const int p = 32 * wave + lr;
+        const int row = (p < L) ? p : ZROW;
+        const char* bbase = smem + OFF_HB + row * ROWB;
+        const int bm = (half ^ (row & 15)) << 4;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+          const bf16v8 av = *(const bf16v8*)(abase + ((32 * ks) ^ am));
+          const bf16v8 bv = *(const bf16v8*)(bbase + ((32 * ks) ^ bm));
+          lg = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, lg, 0, 0, 0);
+        }
+        const float* hb2 = a.vecs + 128 * (1 + 3 * a.n_layers + 1);
+        if (half == 0) {
+          logit[p * 8 + 0] = lg[0] + hb2[0];
+          logit[p * 8 + 1] = lg[1] + hb2[1];
+          logit[p * 8 + 2] = lg[2] + hb2[2];
+          logit[p * 8 + 3] = lg[3] + hb2[3];
+        } else {
+          logit[p * 8 + 4] = lg[0] + hb2[4];
+        }
+      }
+    }
+    END_STAGE();
+
+    // ---- reverse step on this sequence's 200 positions --------------------------------------
+    if (tid < L) {
+      const int p = tid;
+      float lgv[DRK_V];
+#pragma unroll
+      for (int v = 0; v < DRK_V; ++v) lgv[v] = logit[p * 8 + v];
+      if (a.logits_out && f == a.dump_fwd) {
+#pragma unroll
+        for (int v = 0; v < DRK_V; ++v) a.logits_out[(b * L + p) * DRK_V + v] = lgv[v];
+      }
+      const int tk = tok[p];
+      if (f < a.num_steps) {
+        if (tk == DRK_MASK) {
+          float lp[DRK_V], q[DRK_V], u[DRK_V];
+          if (a.uniforms) {
+#pragma unroll
+            for (int v = 0; v < DRK_V; ++v) u[v] = a.uniforms[(((long)f * a.B + b) * L + p) * DRK_V + v];
+          } else {
+            drk_step_uniforms(a.seed, (uint32_t)f, sample, (uint32_t)p, u);
+          }
+          drk_subs_logp(lgv, DRK_MASK, lp);
+          drk_posterior(lp, a.mc_table[2 * f], a.mc_table[2 * f + 1], q);
+          tok[p] = drk_gumbel_argmax(q, u);
+        }
+      } else {  // noise removal: SUBS, argmax over the four nucleotides
+        float lp[DRK_V];
+        drk_subs_logp(lgv, tk, lp);
+        int best = 0;
+#pragma unroll
+        for (int v = 1; v < DRK_V - 1; ++v)
+          if (lp[v] > lp[best]) best = v;
+        tok[p] = best;
+      }
+    }
+    __syncthreads();
+  }
+  if (tid < L) a.x_out[b * L + tid] = tok[tid];
+}
+
+// ------------------------------------------------------------------------------------ C ABI
+extern "C" int drk_sample_bf16(const void* wstream, const float* vecs, const float* tbias, long tb_fwd_stride,
+                               const float* mc_table, const float* uniforms, const int64_t* x_init, int64_t* x_out,
+                               float* logits_out, int dump_fwd, float* dbg_feat, int dbg_layer, int B, int L, int num_steps, int n_layers,
+                               const int* dilations, int noise_removal, uint64_t seed, uint64_t sample_offset,
+                               void* stream) {
+  if (B < 0 || L <= 0) return drk_set_error_msg(DRK_EINVAL, "drk_sample_bf16: bad shape");
+  if (B == 0) return DRK_OK;
+  if (L > MAXPOS) return drk_set_error_msg(DRK_EINVAL, "drk_sample_bf16: L > 224 is not supported by the fused loop");
+  if (n_layers < 1 || n_layers > 32 || num_steps < 0 || (num_steps == 0 && !noise_removal))
+    return drk_set_error_msg(DRK_EINVAL, "drk_sample_bf16: bad n_layers / num_steps");
+  if (!wstream || !vecs || !tbias || !x_out || !dilations || (num_steps > 0 && !mc_table))
+    return drk_set_error_msg(DRK_EINVAL, "drk_sample_bf16: null pointer");
+  SampleArgs a;
+  a.wstream = (const char*)wstream; a.vecs = vecs; a.tbias = tbias; a.tb_fwd_stride = tb_fwd_stride;
+  a.mc_table = mc_table; a.uniforms = uniforms; a.x_init = x_init; a.x_out = x_out; a.logits_out = logits_out;
+  a.dump_fwd = dump_fwd; a.dbg_feat = dbg_feat; a.dbg_layer = dbg_layer; a.B = B; a.L = L; a.num_steps = num_steps; a.n_layers = n_layers;
+  a.noise_removal = noise_removal ? 1 : 0; a.seed = seed; a.sample_offset = sample_offset;
+  for (int i = 0; i < 4; ++i) a.dilpk[i] = 0;
+  for (int i = 0; i < n_layers; ++i) {
+    if (dilations[i] < 0 || dilations[i] > 255) return drk_set_error_msg(DRK_EINVAL, "drk_sample_bf16: dilation out of range");
+    a.dilpk[i >> 3] |= (unsigned long long)dilations[i] << (8 * (i & 7));
+  }
+  {  // per device, cheap, and not an allocation: lets the launch ask for more than 64 KB of LDS
+    hipError_t e = hipFuncSetAttribute((const void*)k_sample_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (e != hipSuccess) return drk_set_error(e, "drk_sample_bf16(hipFuncSetAttribute)");
+  }
+  hipLaunchKernelGGL(k_sample_bf16, dim3(B), dim3(512), LDS_BYTES, (hipStream_t)stream, a);
+  DRK_CHECK_LAUNCH();
+  return DRK_OK;
+}

@@ -1,0 +1,120 @@
+"""Host side of the bf16 fast path: packs the denoiser for drk_sample_bf16 (the fused sampling
+loop, drakes_amd/csrc/drk_sample_bf16.hip) and launches it.
+
+Weight stream layout (what the kernel's LDS-DMA copies verbatim, stage after stage):
+    stage = [128 rows][128 cols] bf16 = 32 KB, 16-byte chunks XOR-swizzled by (row & 15);
+    order = stem (row co, col 5*tap+v), then for each layer its 9 taps (row co, col ci),
+            final_conv.0 (row co, col ci), final_conv.2 (rows 0..4).
+"""
+import ctypes
+
+import torch
+
+from . import _lib, ops
+
+MAX_L = 224
+
+
+def _swizzle_stage(m):
+    """[128][128] float -> bf16 with chunk c of row r stored at chunk c ^ (r & 15)."""
+    r = torch.arange(128, device=m.device)[:, None]
+    c = torch.arange(128, device=m.device)[None, :]
+    dest = (((c >> 3) ^ (r & 15)) << 3) | (c & 7)
+    out = torch.empty(128, 128, dtype=torch.bfloat16, device=m.device)
+    out.scatter_(1, dest.expand(128, 128), m.to(torch.bfloat16))
+    return out
+
+
+def pack_stream(bb):
+    """bb: models.dnaconv.CNNModel -> dict of device tensors the fused kernel reads."""
+    dev = bb.linear.weight.device
+    n = bb.num_layers
+    with torch.no_grad():
+        stages = []
+        stem = torch.zeros(128, 128, device=dev)
+        # linear.weight [co][v][tap] -> col 5*tap + v
+        stem[:, :45] = bb.linear.weight.permute(0, 2, 1).reshape(128, 45)
+        stages.append(_swizzle_stage(stem))
+        for i in range(n):
+            w = bb.convs[i].weight          # [co][ci][tap]
+            for t in range(9):
+                stages.append(_swizzle_stage(w[:, :, t]))
+        stages.append(_swizzle_stage(bb.final_conv[0].weight[:, :, 0]))
+        head2 = torch.zeros(128, 128, device=dev)
+        head2[:ops.V] = bb.final_conv[2].weight[:, :, 0]
+        stages.append(_swizzle_stage(head2))
+        vec_rows = [bb.linear.bias]
+        for i in range(n):
+            vec_rows += [bb.norms[i].weight, bb.norms[i].bias, bb.convs[i].bias]
+        vec_rows.append(bb.final_conv[0].bias)
+        hb2 = torch.zeros(128, device=dev)
+        hb2[:ops.V] = bb.final_conv[2].bias
+        vec_rows.append(hb2)
+        return {
+            'wstream': torch.stack(stages).contiguous(),
+            'vecs': torch.stack([v.detach().float() for v in vec_rows]).contiguous(),
+            'dil': (ctypes.c_int * n)(*[bb.dilation(i) for i in range(n)]),
+            'n_layers': n,
+        }
+
+
+def _packed(bb):
+    key = bb._weights_key()
+    if getattr(bb, '_stream_key', None) != key:
+        bb._stream = pack_stream(bb)
+        bb._stream_key = key
+    return bb._stream
+
+
+def _launch(bb, tbias, tb_stride, mc, uniforms, x_init, x_out, logits_out, dump_fwd, B, L, num_steps, noise_removal,
+            seed, sample_offset, dbg_feat=None, dbg_layer=0):
+    pk = _packed(bb)
+    P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    args = (P(pk['wstream']), P(pk['vecs']), P(tbias), tb_stride, P(mc), P(uniforms), P(x_init), P(x_out),
+            P(logits_out), dump_fwd, P(dbg_feat), dbg_layer, B, L, num_steps, pk['n_layers'], pk['dil'], 1 if noise_removal else 0, seed,
+            sample_offset, ops._stream())
+    flop = 2.0 * B * L * (45 * 128 + pk['n_layers'] * 9 * 128 * 128 + 128 * 128 + 128 * 5) * (num_steps + (1 if noise_removal else 0))
+    ops.PROFILE.bracket('k_sample_bf16', flop, lambda: _lib.call('drk_sample_bf16', *args))
+
+
+def sample_bf16(model, x, table, sigma_last, seed, sample_offset, uniforms):
+    """Diffusion._sample on the fused kernel.  x: int64 [B,L] prior on the device."""
+    bb = model.backbone
+    B, L = x.shape
+    if L > MAX_L:
+        raise NotImplementedError(f'the fused bf16 loop holds one sequence per workgroup in LDS: L <= {MAX_L} '
+                                  f"(got {L}); use hip_dtype='fp32'")
+    dev = x.device
+    num_steps = len(table)
+    noise_removal = bool(model.config.sampling.noise_removal)
+    if model.time_conditioning:
+        sig = [row[1] for row in table] + [sigma_last]
+        tbias = bb.time_bias(torch.tensor(sig, dtype=torch.float32, device=dev))
+        tb_stride = tbias.stride(0)
+    else:
+        tbias = bb.time_bias(torch.zeros(1, dtype=torch.float32, device=dev))
+        tb_stride = 0
+    mc = torch.tensor([[row[2], row[3]] for row in table], dtype=torch.float32, device=dev)
+    u = None
+    if uniforms is not None:
+        u = torch.stack([uniforms(i) for i in range(num_steps)]).contiguous()
+        assert u.shape == (num_steps, B, L, ops.V) and u.dtype == torch.float32
+    out = torch.empty_like(x)
+    _launch(bb, tbias, tb_stride, mc, u, x, out, None, -1, B, L, num_steps, noise_removal, seed, sample_offset)
+    return out
+
+
+def backbone_logits_bf16(bb, x, sigma_scalar=0.0, dbg_layer=None):
+    """Raw logits [B,L,5] of ONE denoiser forward on the fused kernel's arithmetic (int tokens,
+    one sigma for the whole batch).  Used by the parity tests of the bf16 path."""
+    B, L = x.shape
+    dev = x.device
+    tbias = bb.time_bias(torch.full((1,), float(sigma_scalar), dtype=torch.float32, device=dev))
+    logits = torch.empty(B, L, ops.V, dtype=torch.float32, device=dev)
+    out = torch.empty_like(x)
+    if dbg_layer is not None:
+        feat = torch.zeros(B, L, ops.C, dtype=torch.float32, device=dev)
+        _launch(bb, tbias, 0, None, None, x.contiguous(), out, logits, 0, B, L, 0, True, 0, 0, feat, dbg_layer)
+        return logits, out, feat
+    _launch(bb, tbias, 0, None, None, x.contiguous(), out, logits, 0, B, L, 0, True, 0, 0)
+    return logits, out

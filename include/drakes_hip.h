@@ -90,6 +90,28 @@ int drk_conv_fwd_f32(const float* h, const float* w_pk, const float* bias, const
 int drk_head_out_fwd(const float* y, const float* w, const float* bias, float* logits, int B, int L,
                      void* stream);
 
+/* ---- fused sampling loop, bf16 MFMA ----------------------------------------------------------- */
+/* The whole of Diffusion._sample (diffusion_gosai_update.py:506-550, ddpm predictor) in one launch:
+ * num_steps x (CNNModel.forward + _subs_parameterization + _ddpm_update tail) and, if
+ * noise_removal, the final forward + argmax (:541-549).  One workgroup per sequence; L <= 224.
+ *   wstream   bf16 weight stages (layout: drakes_amd/fastpath.py::pack_stream)
+ *   vecs      float32 [3*n_layers+3][128] biases and LayerNorm affine terms (same file)
+ *   tbias     float32 [n_tb][n_layers][128] time biases (drk_time_bias_fwd); forward f reads row
+ *             f * tb_fwd_stride / (n_layers*128) (stride 0: time_conditioning=False)
+ *   mc_table  float32 [num_steps][2] = (move_chance_t, move_chance_s) per step
+ *   uniforms  NULL (in-kernel Philox) or float32 [num_steps][B][L][5]
+ *   x_init    NULL (all-mask prior, :438-440) or int64 [B][L];  x_out int64 [B][L]
+ *   logits_out NULL or float32 [B][L][5]: raw logits of forward number dump_fwd (tests)
+ *   dbg_feat  NULL or float32 [B][L][128]: residual stream of forward dump_fwd after layer
+ *             dbg_layer (-1 = after the stem) (tests)
+ * num_steps may be 0 with noise_removal=1: one forward + argmax from x_init. */
+int drk_sample_bf16(const void* wstream, const float* vecs, const float* tbias, long tb_fwd_stride,
+                    const float* mc_table, const float* uniforms, const int64_t* x_init, int64_t* x_out,
+                    float* logits_out, int dump_fwd, float* dbg_feat, int dbg_layer, int B, int L,
+                    int num_steps, int n_layers,
+                    const int* dilations, int noise_removal, uint64_t seed, uint64_t sample_offset,
+                    void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,149 @@
+"""The fused bf16 sampling kernel (drk_sample_bf16).
+
+Floating-point bar.  End to end, logits must lie within 6e-2 (max) / 1e-2 (rms) of the fp32
+reference logits (|logit| ~ 2; the CPU emulation of the kernel's rounding points,
+oracle/bf16_emulation.py, sits 1.5e-2 / 4e-3 from fp32).  Rounding h to bf16 is discontinuous,
+so two correct bf16 implementations drift apart layer by layer (a last-bit difference flips a
+rounding, the flip is a full bf16 ulp); a tight bound therefore exists only per layer: with every
+other conv zeroed, the residual stream after the layer under test must match the emulation to
+1e-3 (one flip ~ 2e-4), for each of the four dilations, and the stem must match exactly.
+Integer bar: given the kernel's own logits, the fused reverse step must reproduce the oracle's
+tokens bit-exactly."""
+import numpy as np
+import pytest
+import torch
+
+import drakes_amd
+from conftest import load_golden
+from drakes_amd import fastpath, ops
+from oracle import bf16_emulation as E
+from oracle import drakes_oracle as O
+from oracle import philox
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('B,L', [(4, 200), (3, 64), (2, 33), (1, 224), (5, 9)])
+def test_fused_forward_logits(gpu_model, dev, det_sd, B, L):
+    gen = np.random.Generator(np.random.PCG64(100 + L))
+    x = torch.from_numpy(gen.integers(0, 5, (B, L)))
+    x[0] = 4
+    with torch.no_grad():
+        emu = E.cnn_forward_bf16(det_sd, x, torch.zeros(B)).numpy()
+        ref = O.cnn_forward(det_sd, x, torch.zeros(B)).numpy()
+    logits, toks = fastpath.backbone_logits_bf16(gpu_model.backbone, x.to(dev))
+    got = logits.cpu().numpy()
+    print(f'L={L}: max|kernel-emulation|={np.abs(got - emu).max():.2e}  max|kernel-fp32|={np.abs(got - ref).max():.2e}')
+    np.testing.assert_allclose(got, ref, rtol=0, atol=6e-2)
+    assert np.sqrt(((got - ref) ** 2).mean()) < 1e-2
+    assert np.sqrt(((got - emu) ** 2).mean()) < 1e-2
+    # noise-removal argmax on the kernel's own logits: exact
+    want = O.subs_parameterization(logits.cpu().clone(), x)[:, :, :-1].argmax(-1)
+    assert torch.equal(toks.cpu(), want)
+
+
+@pytest.mark.parametrize('layer', [-1, 0, 7, 8, 12, 16, 19])
+def test_fused_single_layer_tight(dev, det_sd, layer):
+    """All convs except `layer` zeroed: the stream after it must match the emulation tightly.
+    Covers the stem (exact) and dilations 1, 4, 16, 64 incl. their all-padding taps."""
+    sd = {k: v.clone() for k, v in det_sd.items()}
+    for i in range(20):
+        if i != layer:
+            sd[f'backbone.convs.{i}.weight'].zero_()
+            sd[f'backbone.convs.{i}.bias'].zero_()
+    m = drakes_amd.Diffusion(drakes_amd.default_config()).to(dev)
+    m.load_state_dict(sd)
+    gen = np.random.Generator(np.random.PCG64(17))
+    B, L = 3, 200
+    x = torch.from_numpy(gen.integers(0, 5, (B, L)))
+    x[0] = 4
+    _, _, feat = fastpath.backbone_logits_bf16(m.backbone, x.to(dev), dbg_layer=layer)
+    got = feat.cpu()
+    # emulation of stem + that one layer (the zeroed layers are identities on the stream)
+    import torch.nn.functional as F
+    with torch.no_grad():
+        f0 = F.relu(F.conv1d(F.one_hot(x, 5).float().permute(0, 2, 1), E.r16(sd['backbone.linear.weight']),
+                             sd['backbone.linear.bias'], padding=4))
+        want = f0
+        if layer >= 0:
+            d = O.layer_dilation(layer, 20)
+            temb = O.time_embedding(sd, torch.zeros(B))
+            tb = F.linear(temb, sd[f'backbone.time_layers.{layer}.dense.weight'],
+                          sd[f'backbone.time_layers.{layer}.dense.bias'])
+            h = F.layer_norm((f0 + tb[:, :, None]).permute(0, 2, 1), (128,), sd[f'backbone.norms.{layer}.weight'],
+                             sd[f'backbone.norms.{layer}.bias'])
+            c = F.relu(F.conv1d(E.r16(h).permute(0, 2, 1), E.r16(sd[f'backbone.convs.{layer}.weight']),
+                                sd[f'backbone.convs.{layer}.bias'], dilation=d, padding=4 * d))
+            want = c + f0
+    want = want.permute(0, 2, 1)
+    err = (got - want).abs()
+    print(f'layer {layer}: max {err.max().item():.2e} rms {err.pow(2).mean().sqrt().item():.2e}')
+    if layer < 0:
+        assert torch.equal(got, want)
+    else:
+        assert err.max().item() < 1e-3 and err.pow(2).mean().sqrt().item() < 5e-5
+
+
+def test_fused_step_exact_on_own_logits(gpu_model, dev):
+    """num_steps=1, no noise removal: x_out must equal the oracle's hard step applied to the
+    logits the kernel dumped, for injected and for in-kernel uniforms."""
+    bb = gpu_model.backbone
+    B, L, seed = 6, 200, 909
+    gen = np.random.Generator(np.random.PCG64(8))
+    x = torch.from_numpy(gen.integers(0, 5, (B, L)))
+    x[0] = 4
+    x[1, ::3] = 4
+    tab = O.step_scalars(128)
+    tbias = bb.time_bias(torch.zeros(1, device=dev))
+    for step_row in (0, 64, 127):
+        mc = tab[step_row, 2:4].reshape(1, 2).contiguous().to(dev)
+        u = torch.from_numpy(philox.step_uniforms(seed, 0, B, L))
+        for inject in (False, True):
+            logits = torch.empty(B, L, 5, device=dev)
+            out = torch.empty(B, L, dtype=torch.int64, device=dev)
+            fastpath._launch(bb, tbias, 0, mc, u.to(dev).reshape(1, B, L, 5).contiguous() if inject else None,
+                             x.to(dev), out, logits, 0, B, L, 1, False, seed, 0)
+            want = O.hard_step_from_logits(logits.cpu().clone(), x, u, tab[step_row, 2], tab[step_row, 3])
+            assert torch.equal(out.cpu(), want), (step_row, inject)
+
+
+def test_fused_sample_vs_reference_tokens(gpu_model, dev):
+    g = load_golden('f4_sample.npz')
+    seed = int(g['useed'])
+    gpu_model.hip_dtype = 'bf16'
+    try:
+        toks = gpu_model._sample(eval_sp_size=8, seed=seed).cpu()
+        toks_inj = gpu_model._sample(eval_sp_size=8, seed=1,
+                                     uniforms=lambda i: ops.step_uniforms(8, 200, seed, i, 0, device=dev)).cpu()
+        part = gpu_model._sample(eval_sp_size=4, seed=seed, sample_offset=4).cpu()
+    finally:
+        gpu_model.hip_dtype = 'fp32'
+    assert toks.dtype == torch.int64 and toks.shape == (8, 200) and toks.min() >= 0 and toks.max() <= 3
+    assert torch.equal(toks, toks_inj)
+    assert torch.equal(toks[4:], part)          # shard invariance
+    want = torch.from_numpy(g['tokens'])
+    rate = (toks != want).float().mean().item()
+    print(f'bf16 fused sampler vs fp32 reference tokens: mismatch rate {rate:.4f}')
+    # bf16 logits flip near-ties and a flip feeds back; this is a sanity bound, not parity
+    assert rate < 0.5
+    # state after 32 steps is still mostly masked in both: compare the unmasked count
+    assert abs(int((toks != 4).sum()) - int((want != 4).sum())) == 0
+
+
+def test_fused_sample_time_conditioned(dev, det_sd):
+    m = drakes_amd.Diffusion(drakes_amd.default_config(time_conditioning=True, steps=16)).to(dev)
+    m.load_state_dict(det_sd)
+    a = m._sample(eval_sp_size=4, seed=3).cpu()
+    m.hip_dtype = 'bf16'
+    b = m._sample(eval_sp_size=4, seed=3).cpu()
+    rate = (a != b).float().mean().item()
+    print('bf16 vs fp32 kernels, time-conditioned, 16 steps: mismatch', rate)
+    assert rate < 0.25
+
+
+def test_fused_rejects_long_sequences(dev, det_sd):
+    m = drakes_amd.Diffusion(drakes_amd.default_config(length=1024, steps=2)).to(dev)
+    m.load_state_dict(det_sd)
+    m.hip_dtype = 'bf16'
+    with pytest.raises(NotImplementedError):
+        m._sample(eval_sp_size=1, seed=0)
