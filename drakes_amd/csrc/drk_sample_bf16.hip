@@ -39,11 +39,13 @@ typedef __bf16 bf16v4 __attribute__((ext_vector_type(4)));
 #define OFF_PART (OFF_WB1 + STAGE_BYTES)            // float2 [4][224]
 #define OFF_LOG (OFF_PART + 4 * MAXPOS * 8)         // float [224][8]
 #define OFF_TOK (OFF_LOG + MAXPOS * 8 * 4)          // int [224]
-#define LDS_BYTES (OFF_TOK + MAXPOS * 4)            // 138368
+#define OFF_VEC (OFF_TOK + MAXPOS * 4)              // float [4][128]: the layer's per-channel vectors
+#define LDS_BYTES (OFF_VEC + 4 * 128 * 4)           // 140416
 
 struct SampleArgs {
   const char* wstream;      // stages, bf16, pre-swizzled: stem, n_layers*9 taps, head0, head2
-  const float* vecs;        // [2 + 3*n_layers + 1][128]: stem bias; per layer gamma,beta,conv bias; head0 bias; head2 bias
+  const float* vecs;        // [n_layers+1] blocks of [3][128]: block 0 = stem bias, gamma_0, beta_0; block k+1 =
+                            // conv bias_k, gamma_{k+1}, beta_{k+1}; the last block = conv bias_{n-1}, head0 bias, head2 bias
   const float* tbias;       // [n_tb][n_layers][128]
   long tb_fwd_stride;       // floats between consecutive forwards' rows (0: one row for all)
   const float* mc_table;    // [num_steps][2] = (move_chance_t, move_chance_s)
@@ -69,6 +71,20 @@ __device__ __forceinline__ void prefetch_stage(const char* __restrict__ src, cha
   }
 }
 
+// Per-channel vectors of epilogue `blk` -> LDS: rows 0..2 from vecs block `blk`, row 3 = time bias of LayerNorm `blk`.
+// 2 KB = two 1-KB wave instructions (waves 0 and 1); rides on the same vmcnt/barrier as the weight stages.
+__device__ __forceinline__ void prefetch_vecs(const float* __restrict__ vblock, const float* __restrict__ tb, char* smem,
+                                              int wave, int lane) {
+  if (wave == 0) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)vblock + lane * 16),
+                                     (__attribute__((address_space(3))) void*)(smem + OFF_VEC), 16, 0, 0);
+  } else if (wave == 1) {
+    const char* src = (lane < 32) ? ((const char*)vblock + 1024 + lane * 16) : ((const char*)tb + (lane - 32) * 16);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(smem + OFF_VEC + 1024), 16, 0, 0);
+  }
+}
+
 __device__ __forceinline__ void stage_sync() {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -76,36 +92,52 @@ __device__ __forceinline__ void stage_sync() {
 
 // ---- one weight stage (= one tap, or a 1x1 conv) --------------------------------------------
 // acc[t] += W_stage[co tile] . h[rows of tile t shifted by `off`], K = 16*KS channels.
-template <int KS>
+// Fragments of k-step ks+1 are read from LDS before the MFMAs of k-step ks are issued.
+template <int NT>
+struct Frags {
+  bf16v8 a;
+  bf16v8 b[NT];
+};
+
+template <int KS, int NT>
 __device__ __forceinline__ void mma_stage(const char* smem, int wb_off, int off, int L, int lr, int half, int ct,
-                                          int grp, int nt, f32x16 (&acc)[4]) {
+                                          int grp, f32x16 (&acc)[NT]) {
   const int arow = 32 * ct + lr;
   const char* abase = smem + wb_off + arow * ROWB;
   const int am = (half ^ (arow & 15)) << 4;
-  const char* bbase[4];
-  int bm[4];
+  const char* bbase[NT];
+  int bm[NT];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
+  for (int t = 0; t < NT; ++t) {
     const int pp = 32 * (grp + 2 * t) + lr + off;
     const int row = ((unsigned)pp < (unsigned)L) ? pp : ZROW;
     bbase[t] = smem + OFF_HB + row * ROWB;
     bm[t] = (half ^ (row & 15)) << 4;
   }
+  Frags<NT> cur, nxt;
+  cur.a = *(const bf16v8*)(abase + (0 ^ am));
+#pragma unroll
+  for (int t = 0; t < NT; ++t) cur.b[t] = *(const bf16v8*)(bbase[t] + (0 ^ bm[t]));
+  __builtin_amdgcn_sched_group_barrier(0x100, NT + 1, 0);   // DS reads of k-step 0
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
-    const bf16v8 a = *(const bf16v8*)(abase + ((32 * ks) ^ am));
+    if (ks + 1 < KS) {
+      nxt.a = *(const bf16v8*)(abase + ((32 * (ks + 1)) ^ am));
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      if (t < nt) {
-        const bf16v8 b = *(const bf16v8*)(bbase[t] + ((32 * ks) ^ bm[t]));
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t], 0, 0, 0);
-      }
+      for (int t = 0; t < NT; ++t) nxt.b[t] = *(const bf16v8*)(bbase[t] + ((32 * (ks + 1)) ^ bm[t]));
     }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.a, cur.b[t], acc[t], 0, 0, 0);
+    // pin the order: the next k-step's LDS reads are issued BEFORE this k-step's MFMAs
+    if (ks + 1 < KS) __builtin_amdgcn_sched_group_barrier(0x100, NT + 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);
+    if (ks + 1 < KS) cur = nxt;
   }
 }
 
-// 16 per-channel values of this lane: channels 32ct + 8g + 4half + e  <->  register 4g + e.
-__device__ __forceinline__ void load_vec16(const float* __restrict__ v, int ct, int half, float (&o)[16]) {
+// 16 per-channel values of this lane from LDS vector row `r`: channels 32ct + 8g + 4half + e  <->  register 4g + e.
+__device__ __forceinline__ void load_vec16(const char* smem, int r, int ct, int half, float (&o)[16]) {
+  const float* v = (const float*)(smem + OFF_VEC) + 128 * r;
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     const f32x4 q = *(const f32x4*)(v + 32 * ct + 8 * g + 4 * half);
@@ -126,82 +158,77 @@ __device__ __forceinline__ void store_h16(char* smem, int p, int ct, int half, c
 }
 
 // LayerNorm of (feat + tbias) over the 128 channels of each position -> h image (bf16).
-// Two barriers inside: partial sums out, h visible.
-__device__ __forceinline__ void layernorm_to_h(char* smem, const f32x16 (&feat)[4], const float* __restrict__ tb,
-                                               const float* __restrict__ gamma, const float* __restrict__ beta, int L,
-                                               int lr, int half, int ct, int grp, int nt) {
+// Vectors come from the LDS block: row 1 gamma, row 2 beta, row 3 time bias.  Two barriers inside.
+template <int NT>
+__device__ __forceinline__ void layernorm_to_h(char* smem, const f32x16 (&feat)[NT], int L, int lr, int half, int ct,
+                                               int grp) {
   float tbv[16];
-  load_vec16(tb, ct, half, tbv);
+  load_vec16(smem, 3, ct, half, tbv);
   float2* part = (float2*)(smem + OFF_PART);
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    if (t < nt) {
-      float s1 = 0.f, s2 = 0.f;
+  for (int t = 0; t < NT; ++t) {
+    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const float x = feat[t][i] + tbv[i];
-        s1 += x;
-        s2 += x * x;
-      }
-      s1 += __shfl_xor(s1, 32);
-      s2 += __shfl_xor(s2, 32);
-      if (half == 0) part[ct * MAXPOS + 32 * (grp + 2 * t) + lr] = make_float2(s1, s2);
+    for (int i = 0; i < 16; ++i) {
+      const float x = feat[t][i] + tbv[i];
+      s1 += x;
+      s2 += x * x;
     }
+    s1 += __shfl_xor(s1, 32);
+    s2 += __shfl_xor(s2, 32);
+    if (half == 0) part[ct * MAXPOS + 32 * (grp + 2 * t) + lr] = make_float2(s1, s2);
   }
   __syncthreads();   // also: every wave is past its last read of the previous h image
   float gv[16], bv[16];
-  load_vec16(gamma, ct, half, gv);
-  load_vec16(beta, ct, half, bv);
+  load_vec16(smem, 1, ct, half, gv);
+  load_vec16(smem, 2, ct, half, bv);
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    if (t < nt) {
-      const int p = 32 * (grp + 2 * t) + lr;
-      float s1 = 0.f, s2 = 0.f;
+  for (int t = 0; t < NT; ++t) {
+    const int p = 32 * (grp + 2 * t) + lr;
+    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const float2 q = part[c * MAXPOS + p];
-        s1 += q.x;
-        s2 += q.y;
-      }
-      const float mean = s1 * (1.0f / 128.0f);
-      const float var = fmaxf(s2 * (1.0f / 128.0f) - mean * mean, 0.0f);
-      const float rstd = 1.0f / sqrtf(var + 1e-5f);
-      float hv[16];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) hv[i] = (feat[t][i] + tbv[i] - mean) * rstd * gv[i] + bv[i];
-      if (p < L) store_h16(smem, p, ct, half, hv);
+    for (int c = 0; c < 4; ++c) {
+      const float2 q = part[c * MAXPOS + p];
+      s1 += q.x;
+      s2 += q.y;
     }
+    const float mean = s1 * (1.0f / 128.0f);
+    const float var = fmaxf(s2 * (1.0f / 128.0f) - mean * mean, 0.0f);
+    const float rstd = 1.0f / sqrtf(var + 1e-5f);
+    float hv[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) hv[i] = (feat[t][i] + tbv[i] - mean) * rstd * gv[i] + bv[i];
+    if (p < L) store_h16(smem, p, ct, half, hv);
   }
   __syncthreads();
 }
 
-__device__ __forceinline__ void dump_feat(float* __restrict__ dst, long b, int L, const f32x16 (&feat)[4], int lr, int half,
-                                          int ct, int grp, int nt) {
+template <int NT>
+__device__ __forceinline__ void dump_feat(float* __restrict__ dst, long b, int L, const f32x16 (&feat)[NT], int lr,
+                                          int half, int ct, int grp) {
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    if (t < nt) {
-      const int p = 32 * (grp + 2 * t) + lr;
-      if (p < L) {
+  for (int t = 0; t < NT; ++t) {
+    const int p = 32 * (grp + 2 * t) + lr;
+    if (p < L) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          f32x4 q = {feat[t][4 * g], feat[t][4 * g + 1], feat[t][4 * g + 2], feat[t][4 * g + 3]};
-          *(f32x4*)(dst + (b * L + p) * 128 + 32 * ct + 8 * g + 4 * half) = q;
-        }
+      for (int g = 0; g < 4; ++g) {
+        f32x4 q = {feat[t][4 * g], feat[t][4 * g + 1], feat[t][4 * g + 2], feat[t][4 * g + 3]};
+        *(f32x4*)(dst + (b * L + p) * 128 + 32 * ct + 8 * g + 4 * half) = q;
       }
     }
   }
 }
 
-__global__ void __launch_bounds__(512, 2) k_sample_bf16(const SampleArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+#define WB(c) ((c) ? OFF_WB1 : OFF_WB0)
+
+// The body, specialised on the number of position tiles this wave owns (4 for waves 0-3, 3 for
+// waves 4-7).  All 7 position tiles are always computed; positions >= L are never stored.
+template <int NT>
+__device__ __forceinline__ void sample_body(const SampleArgs& a, char* smem, int tid, int wave, int lane) {
   const int lr = lane & 31, half = lane >> 5;
   const int ct = wave & 3, grp = wave >> 2;
   const int L = a.L;
   const int ntiles = (L + 31) >> 5;
-  int nt = 0;
-#pragma unroll
-  for (int t = 0; t < 4; ++t) nt += (grp + 2 * t < ntiles) ? 1 : 0;
   const int n_stages = 1 + 9 * a.n_layers + 2;
   const long b = blockIdx.x;
   const uint64_t sample = a.sample_offset + (uint64_t)b;
@@ -216,7 +243,6 @@ __global__ void __launch_bounds__(512, 2) k_sample_bf16(const SampleArgs a) {
   prefetch_stage(a.wstream, smem, OFF_WB0, tid, wave);
   stage_sync();
 
-#define WB(c) ((c) ? OFF_WB1 : OFF_WB0)
 #define NEXT_STAGE()                                                                              \
   do {                                                                                            \
     const int nxt = (stage + 1 == n_stages) ? 0 : stage + 1;                                      \
@@ -232,112 +258,107 @@ __global__ void __launch_bounds__(512, 2) k_sample_bf16(const SampleArgs a) {
   const int n_fwd = a.num_steps + (a.noise_removal ? 1 : 0);
   for (int f = 0; f < n_fwd; ++f) {
     const float* tb = a.tbias + (long)f * a.tb_fwd_stride;
-    f32x16 feat[4], acc[4];
+    f32x16 feat[NT], acc[NT];
 
     // ---- stem: one-hot(x) [45 -> 48 of K] x W_stem, as 3 MFMA k-steps -----------------------
     NEXT_STAGE();
+    prefetch_vecs(a.vecs, tb, smem, wave, lane);
     {
       const int arow = 32 * ct + lr;
       const char* abase = smem + WB(cur) + arow * ROWB;
       const int am = (half ^ (arow & 15)) << 4;
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
+      for (int t = 0; t < NT; ++t) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-        if (t < nt) {
-          const int p = 32 * (grp + 2 * t) + lr;
-          int nb[9];
+        const int p = 32 * (grp + 2 * t) + lr;
+        int nb[9];
 #pragma unroll
-          for (int k = 0; k < 9; ++k) {
-            const int q = p + k - 4;
-            nb[k] = ((unsigned)q < (unsigned)L) ? tok[q] : 7;
+        for (int k = 0; k < 9; ++k) {
+          const int q = p + k - 4;
+          nb[k] = ((unsigned)q < (unsigned)L) ? tok[q] : 7;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+          const bf16v8 av = *(const bf16v8*)(abase + ((32 * ks) ^ am));
+          bf16v8 bv;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            // k = 16ks + 8half + j = 5*tap + v
+            const int k0 = 16 * ks + j, k1 = k0 + 8;
+            const int t0 = k0 / 5, v0 = k0 % 5, t1 = k1 / 5, v1 = k1 % 5;
+            const bool hit0 = (k0 < 45) && (nb[t0 < 9 ? t0 : 0] == v0);
+            const bool hit1 = (k1 < 45) && (nb[t1 < 9 ? t1 : 0] == v1);
+            bv[j] = (__bf16)((half ? hit1 : hit0) ? 1.0f : 0.0f);
           }
-#pragma unroll
-          for (int ks = 0; ks < 3; ++ks) {
-            const bf16v8 av = *(const bf16v8*)(abase + ((32 * ks) ^ am));
-            bf16v8 bv;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              // k = 16ks + 8half + j = 5*tap + v
-              const int k0 = 16 * ks + j, k1 = k0 + 8;
-              const int t0 = k0 / 5, v0 = k0 % 5, t1 = k1 / 5, v1 = k1 % 5;
-              const bool hit0 = (k0 < 45) && (nb[t0 < 9 ? t0 : 0] == v0);
-              const bool hit1 = (k1 < 45) && (nb[t1 < 9 ? t1 : 0] == v1);
-              bv[j] = (__bf16)((half ? hit1 : hit0) ? 1.0f : 0.0f);
-            }
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[t], 0, 0, 0);
-          }
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[t], 0, 0, 0);
         }
       }
     }
+    END_STAGE();
     {
       float sb[16];
-      load_vec16(a.vecs, ct, half, sb);
+      load_vec16(smem, 0, ct, half, sb);
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) feat[t][i] = fmaxf(acc[t][i] + sb[i], 0.f);
     }
-    END_STAGE();
-    if (a.dbg_feat && f == a.dump_fwd && a.dbg_layer == -1) dump_feat(a.dbg_feat, b, L, feat, lr, half, ct, grp, nt);
-    layernorm_to_h(smem, feat, tb, a.vecs + 128 * 1, a.vecs + 128 * 2, L, lr, half, ct, grp, nt);
+    if (a.dbg_feat && f == a.dump_fwd && a.dbg_layer == -1) dump_feat<NT>(a.dbg_feat, b, L, feat, lr, half, ct, grp);
+    layernorm_to_h<NT>(smem, feat, L, lr, half, ct, grp);
 
-    // ---- 20 x (dilated conv + ReLU + residual, then the next layer's LayerNorm) -------------
+    // ---- n_layers x (dilated conv + ReLU + residual, then the next layer's LayerNorm) --------
     for (int layer = 0; layer < a.n_layers; ++layer) {
       const int dil = (int)((a.dilpk[layer >> 3] >> (8 * (layer & 7))) & 255ull);
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
       for (int tap = 0; tap < 9; ++tap) {
         NEXT_STAGE();
-        mma_stage<8>(smem, WB(cur), (tap - 4) * dil, L, lr, half, ct, grp, nt, acc);
+        if (tap == 0)   // this layer's epilogue vectors; the previous epilogue is past its last read of them
+          prefetch_vecs(a.vecs + 384 * (layer + 1), tb + 128 * ((layer + 1 < a.n_layers) ? layer + 1 : layer), smem, wave,
+                        lane);
+        mma_stage<8, NT>(smem, WB(cur), (tap - 4) * dil, L, lr, half, ct, grp, acc);
         END_STAGE();
       }
       {
         float cb[16];
-        load_vec16(a.vecs + 128 * (1 + 3 * layer + 2), ct, half, cb);
+        load_vec16(smem, 0, ct, half, cb);
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
           for (int i = 0; i < 16; ++i) feat[t][i] += fmaxf(acc[t][i] + cb[i], 0.f);
       }
-      if (a.dbg_feat && f == a.dump_fwd && a.dbg_layer == layer) dump_feat(a.dbg_feat, b, L, feat, lr, half, ct, grp, nt);
-      if (layer + 1 < a.n_layers) {
-        layernorm_to_h(smem, feat, tb + 128 * (layer + 1), a.vecs + 128 * (1 + 3 * (layer + 1)),
-                       a.vecs + 128 * (1 + 3 * (layer + 1) + 1), L, lr, half, ct, grp, nt);
-      }
+      if (a.dbg_feat && f == a.dump_fwd && a.dbg_layer == layer) dump_feat<NT>(a.dbg_feat, b, L, feat, lr, half, ct, grp);
+      if (layer + 1 < a.n_layers) layernorm_to_h<NT>(smem, feat, L, lr, half, ct, grp);
     }
 
     // ---- head: final_conv.0 (1x1) + ReLU, final_conv.2 (128 -> 5) ---------------------------
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      if (t < nt) {
-        const int p = 32 * (grp + 2 * t) + lr;
-        float hv[16];
+    for (int t = 0; t < NT; ++t) {
+      const int p = 32 * (grp + 2 * t) + lr;
+      float hv[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) hv[i] = feat[t][i];
-        if (p < L) store_h16(smem, p, ct, half, hv);
-      }
+      for (int i = 0; i < 16; ++i) hv[i] = feat[t][i];
+      if (p < L) store_h16(smem, p, ct, half, hv);
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
     }
     __syncthreads();
     NEXT_STAGE();
-    mma_stage<8>(smem, WB(cur), 0, L, lr, half, ct, grp, nt, acc);
+    mma_stage<8, NT>(smem, WB(cur), 0, L, lr, half, ct, grp, acc);
     END_STAGE();   // all reads of the feat image are done
     {
       float hb0[16];
-      load_vec16(a.vecs + 128 * (1 + 3 * a.n_layers), ct, half, hb0);
+      load_vec16(smem, 1, ct, half, hb0);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        if (t < nt) {
-          const int p = 32 * (grp + 2 * t) + lr;
-          float hv[16];
+      for (int t = 0; t < NT; ++t) {
+        const int p = 32 * (grp + 2 * t) + lr;
+        float hv[16];
 #pragma unroll
-          for (int i = 0; i < 16; ++i) hv[i] = fmaxf(acc[t][i] + hb0[i], 0.f);
-          if (p < L) store_h16(smem, p, ct, half, hv);
-        }
+        for (int i = 0; i < 16; ++i) hv[i] = fmaxf(acc[t][i] + hb0[i], 0.f);
+        if (p < L) store_h16(smem, p, ct, half, hv);
       }
     }
     __syncthreads();
@@ -360,7 +381,7 @@ __global__ void __launch_bounds__(512, 2) k_sample_bf16(const SampleArgs a) {
           const bf16v8 bv = *(const bf16v8*)(bbase + ((32 * ks) ^ bm));
           lg = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, lg, 0, 0, 0);
         }
-        const float* hb2 = a.vecs + 128 * (1 + 3 * a.n_layers + 1);
+        const float* hb2 = (const float*)(smem + OFF_VEC) + 128 * 2;
         if (half == 0) {
           logit[p * 8 + 0] = lg[0] + hb2[0];
           logit[p * 8 + 1] = lg[1] + hb2[1];
@@ -373,7 +394,7 @@ __global__ void __launch_bounds__(512, 2) k_sample_bf16(const SampleArgs a) {
     }
     END_STAGE();
 
-    // ---- reverse step on this sequence's 200 positions --------------------------------------
+    // ---- reverse step on this sequence's positions ------------------------------------------
     if (tid < L) {
       const int p = tid;
       float lgv[DRK_V];
@@ -410,6 +431,18 @@ __global__ void __launch_bounds__(512, 2) k_sample_bf16(const SampleArgs a) {
     __syncthreads();
   }
   if (tid < L) a.x_out[b * L + tid] = tok[tid];
+#undef NEXT_STAGE
+#undef END_STAGE
+}
+
+__global__ void __launch_bounds__(512, 2) k_sample_bf16(const SampleArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: scalar branches, SGPR tile ids
+  if (wave < 4)
+    sample_body<4>(a, smem, tid, wave, lane);
+  else
+    sample_body<3>(a, smem, tid, wave, lane);
 }
 
 // ------------------------------------------------------------------------------------ C ABI

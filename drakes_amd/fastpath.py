@@ -43,13 +43,16 @@ def pack_stream(bb):
         head2 = torch.zeros(128, 128, device=dev)
         head2[:ops.V] = bb.final_conv[2].weight[:, :, 0]
         stages.append(_swizzle_stage(head2))
-        vec_rows = [bb.linear.bias]
-        for i in range(n):
-            vec_rows += [bb.norms[i].weight, bb.norms[i].bias, bb.convs[i].bias]
-        vec_rows.append(bb.final_conv[0].bias)
+        # epilogue blocks of 3 vectors: block 0 = stem bias, gamma_0, beta_0; block k+1 = conv bias_k,
+        # gamma_{k+1}, beta_{k+1}; last block = conv bias_{n-1}, final_conv.0 bias, final_conv.2 bias (padded)
         hb2 = torch.zeros(128, device=dev)
         hb2[:ops.V] = bb.final_conv[2].bias
-        vec_rows.append(hb2)
+        vec_rows = [bb.linear.bias, bb.norms[0].weight, bb.norms[0].bias]
+        for k in range(n):
+            if k + 1 < n:
+                vec_rows += [bb.convs[k].bias, bb.norms[k + 1].weight, bb.norms[k + 1].bias]
+            else:
+                vec_rows += [bb.convs[k].bias, bb.final_conv[0].bias, hb2]
         return {
             'wstream': torch.stack(stages).contiguous(),
             'vecs': torch.stack([v.detach().float() for v in vec_rows]).contiguous(),

@@ -95,7 +95,7 @@ int drk_head_out_fwd(const float* y, const float* w, const float* bias, float* l
  * num_steps x (CNNModel.forward + _subs_parameterization + _ddpm_update tail) and, if
  * noise_removal, the final forward + argmax (:541-549).  One workgroup per sequence; L <= 224.
  *   wstream   bf16 weight stages (layout: drakes_amd/fastpath.py::pack_stream)
- *   vecs      float32 [3*n_layers+3][128] biases and LayerNorm affine terms (same file)
+ *   vecs      float32 [n_layers+1][3][128] biases and LayerNorm affine terms (same file)
  *   tbias     float32 [n_tb][n_layers][128] time biases (drk_time_bias_fwd); forward f reads row
  *             f * tb_fwd_stride / (n_layers*128) (stride 0: time_conditioning=False)
  *   mc_table  float32 [num_steps][2] = (move_chance_t, move_chance_s) per step
