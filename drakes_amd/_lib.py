@@ -8,7 +8,8 @@ import os
 from ctypes import c_char_p, c_float, c_int, c_long, c_uint32, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libdrakes_hip.so')
+# DRK_LIB: experiment builds (tools/exp.py); the product always loads the in-tree library
+LIB_PATH = os.environ.get('DRK_LIB') or os.path.join(_HERE, 'libdrakes_hip.so')
 
 _P = c_void_p
 
@@ -25,7 +26,7 @@ SIGNATURES = {
     'drk_ln_fwd': [_P, _P, c_long, _P, _P, _P, _P, _P, c_int, c_int, _P],
     'drk_conv_fwd_f32': [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P],
     'drk_head_out_fwd': [_P, _P, _P, _P, c_int, c_int, _P],
-    'drk_sample_bf16': [_P, _P, _P, c_long, _P, _P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, c_int,
+    'drk_sample_bf16': [_P, _P, _P, _P, _P, c_long, _P, _P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, c_int,
                         c_uint64, c_uint64, _P],
 }
 

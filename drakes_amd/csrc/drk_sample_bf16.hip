@@ -28,22 +28,29 @@
 
 typedef __bf16 bf16v8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16v4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) char lds_char;   // LDS-typed pointer: LDS-DMA destinations need no generic->LDS cast
 
 #define ROWB 256                 // bytes per LDS image row (128 bf16)
 #define MAXPOS 224               // 7 position tiles
 #define ZROW 224                 // the all-zero row of the h image
 #define STAGE_BYTES 32768        // one weight stage: [128 rows][128 cols] bf16
+#define STEM_ROWB 128            // resident stem image: [128 co][64 k] bf16 (k = 5*tap + v, 45 used)
 #define OFF_HB 0
 #define OFF_WB0 (OFF_HB + (ZROW + 1) * ROWB)        // 57600
 #define OFF_WB1 (OFF_WB0 + STAGE_BYTES)
-#define OFF_PART (OFF_WB1 + STAGE_BYTES)            // float2 [4][224]
-#define OFF_LOG (OFF_PART + 4 * MAXPOS * 8)         // float [224][8]
+#define OFF_STEM (OFF_WB1 + STAGE_BYTES)            // resident for the whole launch
+#define OFF_HEAD2 (OFF_STEM + 128 * STEM_ROWB)      // resident: [8 rows][128] bf16, rows 5..7 zero
+#define OFF_PART (OFF_HEAD2 + 8 * ROWB)             // float [2][4][224]: per channel-tile sum, sum of squares
+#define OFF_LOG (OFF_PART + 2 * 4 * MAXPOS * 4)     // float [224][8]
 #define OFF_TOK (OFF_LOG + MAXPOS * 8 * 4)          // int [224]
 #define OFF_VEC (OFF_TOK + MAXPOS * 4)              // float [4][128]: the layer's per-channel vectors
-#define LDS_BYTES (OFF_VEC + 4 * 128 * 4)           // 140416
+#define LDS_BYTES (OFF_VEC + 4 * 128 * 4)           // 158848 of 163840
 
 struct SampleArgs {
-  const char* wstream;      // stages, bf16, pre-swizzled: stem, n_layers*9 taps, head0, head2
+  const char* wstream;      // stages, bf16, pre-swizzled: n_layers*9 conv taps, then final_conv.0
+  const char* stem_w;       // [128][64] bf16
+  const char* head2_w;      // [8][128] bf16, chunk-swizzled like a stage
   const float* vecs;        // [n_layers+1] blocks of [3][128]: block 0 = stem bias, gamma_0, beta_0; block k+1 =
                             // conv bias_k, gamma_{k+1}, beta_{k+1}; the last block = conv bias_{n-1}, head0 bias, head2 bias
   const float* tbias;       // [n_tb][n_layers][128]
@@ -62,26 +69,26 @@ struct SampleArgs {
 };
 
 // ---- stage streaming -----------------------------------------------------------------------
-__device__ __forceinline__ void prefetch_stage(const char* __restrict__ src, char* smem, int dst_off, int tid, int wave) {
+__device__ __forceinline__ void prefetch_stage(const char* __restrict__ src, lds_char* lds, int dst_off, int tid, int wave) {
 #pragma unroll
   for (int it = 0; it < STAGE_BYTES / (512 * 16); ++it) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (it * 512 + tid) * 16),
-                                     (__attribute__((address_space(3))) void*)(smem + dst_off + it * 8192 + wave * 1024),
+                                     (__attribute__((address_space(3))) void*)(lds + dst_off + it * 8192 + wave * 1024),
                                      16, 0, 0);
   }
 }
 
-// Per-channel vectors of epilogue `blk` -> LDS: rows 0..2 from vecs block `blk`, row 3 = time bias of LayerNorm `blk`.
-// 2 KB = two 1-KB wave instructions (waves 0 and 1); rides on the same vmcnt/barrier as the weight stages.
-__device__ __forceinline__ void prefetch_vecs(const float* __restrict__ vblock, const float* __restrict__ tb, char* smem,
+// Per-channel vectors of an epilogue -> LDS: rows 0..2 from a vecs block, row 3 = the time bias of the LayerNorm it
+// feeds.  2 KB = two 1-KB wave instructions (waves 0 and 1); rides on the same vmcnt/barrier as the weight stages.
+__device__ __forceinline__ void prefetch_vecs(const float* __restrict__ vblock, const float* __restrict__ tb, lds_char* lds,
                                               int wave, int lane) {
   if (wave == 0) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)vblock + lane * 16),
-                                     (__attribute__((address_space(3))) void*)(smem + OFF_VEC), 16, 0, 0);
+                                     (__attribute__((address_space(3))) void*)(lds + OFF_VEC), 16, 0, 0);
   } else if (wave == 1) {
     const char* src = (lane < 32) ? ((const char*)vblock + 1024 + lane * 16) : ((const char*)tb + (lane - 32) * 16);
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)(smem + OFF_VEC + 1024), 16, 0, 0);
+                                     (__attribute__((address_space(3))) void*)(lds + OFF_VEC + 1024), 16, 0, 0);
   }
 }
 
@@ -90,9 +97,16 @@ __device__ __forceinline__ void stage_sync() {
   __syncthreads();
 }
 
+// Returns `v` through an empty asm: everything derived from the result is recomputed where it is used instead of
+// being hoisted out of the layer/step loops and kept (then spilled) for the whole kernel.
+__device__ __forceinline__ int opaque(int v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+
 // ---- one weight stage (= one tap, or a 1x1 conv) --------------------------------------------
 // acc[t] += W_stage[co tile] . h[rows of tile t shifted by `off`], K = 16*KS channels.
-// Fragments of k-step ks+1 are read from LDS before the MFMAs of k-step ks are issued.
+// Fragments of k-step ks+1 are read from LDS while the MFMAs of k-step ks run.
 template <int NT>
 struct Frags {
   bf16v8 a;
@@ -100,8 +114,10 @@ struct Frags {
 };
 
 template <int KS, int NT>
-__device__ __forceinline__ void mma_stage(const char* smem, int wb_off, int off, int L, int lr, int half, int ct,
-                                          int grp, f32x16 (&acc)[NT]) {
+__device__ __forceinline__ void mma_stage(const char* smem, int wb_off, int off, int L, int lane, int ct, int grp,
+                                          f32x16 (&acc)[NT]) {
+  const int lo = opaque(lane);
+  const int lr = lo & 31, half = lo >> 5;
   const int arow = 32 * ct + lr;
   const char* abase = smem + wb_off + arow * ROWB;
   const int am = (half ^ (arow & 15)) << 4;
@@ -110,7 +126,7 @@ __device__ __forceinline__ void mma_stage(const char* smem, int wb_off, int off,
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int pp = 32 * (grp + 2 * t) + lr + off;
-    const int row = ((unsigned)pp < (unsigned)L) ? pp : ZROW;
+    const int row = ((unsigned)pp < (unsigned)L) ? pp : ZROW;   // 'same' zero padding = the all-zero row
     bbase[t] = smem + OFF_HB + row * ROWB;
     bm[t] = (half ^ (row & 15)) << 4;
   }
@@ -128,9 +144,11 @@ __device__ __forceinline__ void mma_stage(const char* smem, int wb_off, int off,
     }
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.a, cur.b[t], acc[t], 0, 0, 0);
-    // pin the order: the next k-step's LDS reads are issued BEFORE this k-step's MFMAs
+    // Pinned order per k-step: first MFMA (its operand wait covers only reads already a k-step old), then the
+    // next k-step's LDS reads, then the remaining MFMAs, which cover those reads' latency.
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
     if (ks + 1 < KS) __builtin_amdgcn_sched_group_barrier(0x100, NT + 1, 0);
-    __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);
+    if (NT > 1) __builtin_amdgcn_sched_group_barrier(0x008, NT - 1, 0);
     if (ks + 1 < KS) cur = nxt;
   }
 }
@@ -157,14 +175,30 @@ __device__ __forceinline__ void store_h16(char* smem, int p, int ct, int half, c
   }
 }
 
-// LayerNorm of (feat + tbias) over the 128 channels of each position -> h image (bf16).
-// Vectors come from the LDS block: row 1 gamma, row 2 beta, row 3 time bias.  Two barriers inside.
-template <int NT>
-__device__ __forceinline__ void layernorm_to_h(char* smem, const f32x16 (&feat)[NT], int L, int lr, int half, int ct,
-                                               int grp) {
-  float tbv[16];
-  load_vec16(smem, 3, ct, half, tbv);
-  float2* part = (float2*)(smem + OFF_PART);
+// Residual update feat += relu(acc + bias) [or feat = relu(acc + bias) after the stem], then, if `do_ln`, the next
+// layer's LayerNorm of (feat + tbias) over the 128 channels of each position -> h image (bf16).
+// Vectors come from the LDS block: row 0 bias, row 1 gamma, row 2 beta, row 3 time bias.
+// A lane holds 16 of a position's 128 channels per tile: local sums, one half-wave exchange (v_permlane32_swap,
+// which leaves sum in the lower and sum-of-squares in the upper half-wave), four partials through LDS.
+// Two barriers inside when do_ln; the first also orders "all MFMA reads of the old h image" before its overwrite.
+template <int NT, bool ASSIGN>
+__device__ __forceinline__ void epilogue_ln(char* smem, f32x16 (&feat)[NT], const f32x16 (&acc)[NT], bool do_ln, int L,
+                                            int lane, int ct, int grp) {
+#pragma clang fp contract(fast)
+  const int lo = opaque(lane);
+  const int lr = lo & 31, half = lo >> 5;
+  float cb[16], tbv[16];
+  load_vec16(smem, 0, ct, half, cb);
+  if (do_ln) load_vec16(smem, 3, ct, half, tbv);
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float r = fmaxf(acc[t][i] + cb[i], 0.f);
+      feat[t][i] = ASSIGN ? r : feat[t][i] + r;
+    }
+  if (!do_ln) return;
+  float* part = (float*)(smem + OFF_PART);
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     float s1 = 0.f, s2 = 0.f;
@@ -174,30 +208,26 @@ __device__ __forceinline__ void layernorm_to_h(char* smem, const f32x16 (&feat)[
       s1 += x;
       s2 += x * x;
     }
-    s1 += __shfl_xor(s1, 32);
-    s2 += __shfl_xor(s2, 32);
-    if (half == 0) part[ct * MAXPOS + 32 * (grp + 2 * t) + lr] = make_float2(s1, s2);
+    const u32x2 sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(s1), __float_as_uint(s2), false, false);
+    // lower half-wave: s1(lower) + s1(upper); upper half-wave: s2(lower) + s2(upper)
+    part[(half * 4 + ct) * MAXPOS + 32 * (grp + 2 * t) + lr] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
   }
-  __syncthreads();   // also: every wave is past its last read of the previous h image
   float gv[16], bv[16];
   load_vec16(smem, 1, ct, half, gv);
   load_vec16(smem, 2, ct, half, bv);
+  __syncthreads();
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int p = 32 * (grp + 2 * t) + lr;
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const float2 q = part[c * MAXPOS + p];
-      s1 += q.x;
-      s2 += q.y;
-    }
+    const float s1 = (part[0 * MAXPOS + p] + part[1 * MAXPOS + p]) + (part[2 * MAXPOS + p] + part[3 * MAXPOS + p]);
+    const float s2 = (part[4 * MAXPOS + p] + part[5 * MAXPOS + p]) + (part[6 * MAXPOS + p] + part[7 * MAXPOS + p]);
     const float mean = s1 * (1.0f / 128.0f);
     const float var = fmaxf(s2 * (1.0f / 128.0f) - mean * mean, 0.0f);
-    const float rstd = 1.0f / sqrtf(var + 1e-5f);
+    const float rstd = __builtin_amdgcn_rsqf(var + 1e-5f);
+    const float c = -mean * rstd;
     float hv[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) hv[i] = (feat[t][i] + tbv[i] - mean) * rstd * gv[i] + bv[i];
+    for (int i = 0; i < 16; ++i) hv[i] = ((feat[t][i] + tbv[i]) * rstd + c) * gv[i] + bv[i];
     if (p < L) store_h16(smem, p, ct, half, hv);
   }
   __syncthreads();
@@ -221,52 +251,89 @@ __device__ __forceinline__ void dump_feat(float* __restrict__ dst, long b, int L
 
 #define WB(c) ((c) ? OFF_WB1 : OFF_WB0)
 
+// Diagnostic build only (-DDRK_STAMPS, tools/exp.py): per-wave cycle shares of the phases, written to dbg_feat as
+// uint64 [B][8 waves][4] = (mma compute, stage wait+barrier, layer epilogue+LayerNorm, stem/head/step).  Never in the product.
+#ifdef DRK_STAMPS
+#define STAMP(var)                                         \
+  do {                                                     \
+    __builtin_amdgcn_sched_barrier(0);                     \
+    var = __builtin_amdgcn_s_memtime();                    \
+    __builtin_amdgcn_s_waitcnt(0xC07F);                    \
+    __builtin_amdgcn_sched_barrier(0);                     \
+  } while (0)
+#define ACCUM(slot, t0v)                                   \
+  do {                                                     \
+    unsigned long long t1__;                               \
+    STAMP(t1__);                                           \
+    tacc[slot] += t1__ - t0v;                              \
+    t0v = t1__;                                            \
+  } while (0)
+#else
+#define STAMP(var) do {} while (0)
+#define ACCUM(slot, t0v) do {} while (0)
+#endif
+
 // The body, specialised on the number of position tiles this wave owns (4 for waves 0-3, 3 for
 // waves 4-7).  All 7 position tiles are always computed; positions >= L are never stored.
 template <int NT>
-__device__ __forceinline__ void sample_body(const SampleArgs& a, char* smem, int tid, int wave, int lane) {
+__device__ __forceinline__ void sample_body(const SampleArgs& a, char* smem, lds_char* lds, int tid, int wave, int lane) {
   const int lr = lane & 31, half = lane >> 5;
   const int ct = wave & 3, grp = wave >> 2;
   const int L = a.L;
   const int ntiles = (L + 31) >> 5;
-  const int n_stages = 1 + 9 * a.n_layers + 2;
   const long b = blockIdx.x;
   const uint64_t sample = a.sample_offset + (uint64_t)b;
   int* tok = (int*)(smem + OFF_TOK);
   float* logit = (float*)(smem + OFF_LOG);
 
-  // ---- init: tokens, zero row, first stage -------------------------------------------------
+  // A tap whose shift is >= L reads only padding at every position: its stage is skipped altogether
+  // (no load, no barrier, no MFMA).  Live taps of a layer with dilation d: 4-m .. 4+m, m = min(4, (L-1)/d).
+  auto dil_of = [&](int layer) { return (int)((a.dilpk[layer >> 3] >> (8 * (layer & 7))) & 255ull); };
+  auto reach_of = [&](int layer) {
+    const int d = dil_of(layer);
+    const int m = (d > 0) ? (L - 1) / d : 4;
+    return m < 4 ? m : 4;
+  };
+  const int head0_stage = 9 * a.n_layers;
+  const int first_stage = 4 - reach_of(0);
+
+  // ---- init: tokens, zero row, resident stem / final_conv.2 images, first stage ---------------
   for (int i = tid; i < MAXPOS; i += 512) tok[i] = (i < L) ? (a.x_init ? (int)a.x_init[b * L + i] : DRK_MASK) : DRK_MASK;
   if (tid < ROWB / 4) ((int*)(smem + OFF_HB + ZROW * ROWB))[tid] = 0;
-  int stage = 0;      // index into the weight stream (wraps at n_stages)
-  int cur = 0;        // which LDS weight buffer holds `stage`
-  prefetch_stage(a.wstream, smem, OFF_WB0, tid, wave);
+  for (int i = tid; i < 128 * STEM_ROWB / 16; i += 512) ((f32x4*)(smem + OFF_STEM))[i] = ((const f32x4*)a.stem_w)[i];
+  if (tid < 8 * ROWB / 16) ((f32x4*)(smem + OFF_HEAD2))[tid] = ((const f32x4*)a.head2_w)[tid];
+  int stage = first_stage;   // index into the weight stream of the stage resident in WB(cur)
+  int cur = 0;
+  prefetch_stage(a.wstream + (long)stage * STAGE_BYTES, lds, OFF_WB0, tid, wave);
   stage_sync();
 
-#define NEXT_STAGE()                                                                              \
-  do {                                                                                            \
-    const int nxt = (stage + 1 == n_stages) ? 0 : stage + 1;                                      \
-    prefetch_stage(a.wstream + (long)nxt * STAGE_BYTES, smem, WB(cur ^ 1), tid, wave);            \
-  } while (0)
-#define END_STAGE()                                   \
-  do {                                                \
-    stage_sync();                                     \
-    stage = (stage + 1 == n_stages) ? 0 : stage + 1;  \
-    cur ^= 1;                                         \
+#ifdef DRK_EXP_NOSTREAM   // timing experiment only: what the weight stream costs
+#define NEXT_STAGE(nxt) do { (void)(nxt); } while (0)
+#else
+#define NEXT_STAGE(nxt) prefetch_stage(a.wstream + (long)(nxt) * STAGE_BYTES, lds, WB(cur ^ 1), tid, wave)
+#endif
+#define END_STAGE(nxt)  \
+  do {                  \
+    stage_sync();       \
+    stage = (nxt);      \
+    cur ^= 1;           \
   } while (0)
 
+#ifdef DRK_STAMPS
+  unsigned long long tacc[4] = {0, 0, 0, 0}, t0;
+  STAMP(t0);
+#endif
   const int n_fwd = a.num_steps + (a.noise_removal ? 1 : 0);
   for (int f = 0; f < n_fwd; ++f) {
     const float* tb = a.tbias + (long)f * a.tb_fwd_stride;
     f32x16 feat[NT], acc[NT];
 
-    // ---- stem: one-hot(x) [45 -> 48 of K] x W_stem, as 3 MFMA k-steps -----------------------
-    NEXT_STAGE();
-    prefetch_vecs(a.vecs, tb, smem, wave, lane);
+    // ---- stem: one-hot(x) [45 -> 48 of K] x W_stem (LDS-resident), as 3 MFMA k-steps ----------
+    // No weight stage is consumed here: the first conv stage of this forward is already resident.
+    prefetch_vecs(a.vecs, tb, lds, wave, lane);
     {
       const int arow = 32 * ct + lr;
-      const char* abase = smem + WB(cur) + arow * ROWB;
-      const int am = (half ^ (arow & 15)) << 4;
+      const char* abase = smem + OFF_STEM + arow * STEM_ROWB + 16 * half;
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
 #pragma unroll
@@ -280,7 +347,7 @@ __device__ __forceinline__ void sample_body(const SampleArgs& a, char* smem, int
         }
 #pragma unroll
         for (int ks = 0; ks < 3; ++ks) {
-          const bf16v8 av = *(const bf16v8*)(abase + ((32 * ks) ^ am));
+          const bf16v8 av = *(const bf16v8*)(abase + 32 * ks);
           bf16v8 bv;
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
@@ -295,82 +362,79 @@ __device__ __forceinline__ void sample_body(const SampleArgs& a, char* smem, int
         }
       }
     }
-    END_STAGE();
-    {
-      float sb[16];
-      load_vec16(smem, 0, ct, half, sb);
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) feat[t][i] = fmaxf(acc[t][i] + sb[i], 0.f);
-    }
+    stage_sync();   // the vector block has landed
+    epilogue_ln<NT, true>(smem, feat, acc, true, L, lane, ct, grp);
     if (a.dbg_feat && f == a.dump_fwd && a.dbg_layer == -1) dump_feat<NT>(a.dbg_feat, b, L, feat, lr, half, ct, grp);
-    layernorm_to_h<NT>(smem, feat, L, lr, half, ct, grp);
+    ACCUM(3, t0);
 
     // ---- n_layers x (dilated conv + ReLU + residual, then the next layer's LayerNorm) --------
     for (int layer = 0; layer < a.n_layers; ++layer) {
-      const int dil = (int)((a.dilpk[layer >> 3] >> (8 * (layer & 7))) & 255ull);
+      const int dil = dil_of(layer);
+      const int m = reach_of(layer);
+      const int after = (layer + 1 < a.n_layers) ? 9 * (layer + 1) + 4 - reach_of(layer + 1) : head0_stage;
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-      for (int tap = 0; tap < 9; ++tap) {
-        NEXT_STAGE();
-        if (tap == 0)   // this layer's epilogue vectors; the previous epilogue is past its last read of them
-          prefetch_vecs(a.vecs + 384 * (layer + 1), tb + 128 * ((layer + 1 < a.n_layers) ? layer + 1 : layer), smem, wave,
+      for (int tap = 4 - m; tap <= 4 + m; ++tap) {
+        const int nxt = (tap < 4 + m) ? stage + 1 : after;
+        NEXT_STAGE(nxt);
+        if (tap == 4 - m)   // this layer's epilogue vectors; the previous epilogue is past its last read of them
+          prefetch_vecs(a.vecs + 384 * (layer + 1), tb + 128 * ((layer + 1 < a.n_layers) ? layer + 1 : layer), lds, wave,
                         lane);
-        mma_stage<8, NT>(smem, WB(cur), (tap - 4) * dil, L, lr, half, ct, grp, acc);
-        END_STAGE();
+        mma_stage<8, NT>(smem, WB(cur), (tap - 4) * dil, L, lane, ct, grp, acc);
+        ACCUM(0, t0);
+        END_STAGE(nxt);
+        ACCUM(1, t0);
       }
-      {
-        float cb[16];
-        load_vec16(smem, 0, ct, half, cb);
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-          for (int i = 0; i < 16; ++i) feat[t][i] += fmaxf(acc[t][i] + cb[i], 0.f);
-      }
+      epilogue_ln<NT, false>(smem, feat, acc, layer + 1 < a.n_layers, L, lane, ct, grp);
       if (a.dbg_feat && f == a.dump_fwd && a.dbg_layer == layer) dump_feat<NT>(a.dbg_feat, b, L, feat, lr, half, ct, grp);
-      if (layer + 1 < a.n_layers) layernorm_to_h<NT>(smem, feat, L, lr, half, ct, grp);
+      ACCUM(2, t0);
     }
 
     // ---- head: final_conv.0 (1x1) + ReLU, final_conv.2 (128 -> 5) ---------------------------
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const int p = 32 * (grp + 2 * t) + lr;
-      float hv[16];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) hv[i] = feat[t][i];
-      if (p < L) store_h16(smem, p, ct, half, hv);
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-    }
-    __syncthreads();
-    NEXT_STAGE();
-    mma_stage<8, NT>(smem, WB(cur), 0, L, lr, half, ct, grp, acc);
-    END_STAGE();   // all reads of the feat image are done
     {
-      float hb0[16];
-      load_vec16(smem, 1, ct, half, hb0);
+      const int lo_h = opaque(lane);
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        const int p = 32 * (grp + 2 * t) + lr;
+        const int p = 32 * (grp + 2 * t) + (lo_h & 31);
         float hv[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) hv[i] = fmaxf(acc[t][i] + hb0[i], 0.f);
-        if (p < L) store_h16(smem, p, ct, half, hv);
+        for (int i = 0; i < 16; ++i) hv[i] = feat[t][i];
+        if (p < L) store_h16(smem, p, ct, lo_h >> 5, hv);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
       }
     }
     __syncthreads();
-    NEXT_STAGE();
+    // the stage after final_conv.0 is the first conv stage of the NEXT forward: its load runs under the head,
+    // the reverse step and the next stem, none of which needs the stream
+    NEXT_STAGE(first_stage);
+    mma_stage<8, NT>(smem, WB(cur), 0, L, lane, ct, grp, acc);
+    END_STAGE(first_stage);   // all reads of the feat image are done
     {
-      // 5 output rows live in channel tile 0; position tile = wave (waves 0..6)
+      const int lo2 = opaque(lane);
+      float hb0[16];
+      load_vec16(smem, 1, ct, lo2 >> 5, hb0);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int p = 32 * (grp + 2 * t) + (lo2 & 31);
+        float hv[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) hv[i] = fmaxf(acc[t][i] + hb0[i], 0.f);
+        if (p < L) store_h16(smem, p, ct, lo2 >> 5, hv);
+      }
+    }
+    __syncthreads();
+    {
+      // 5 output rows (LDS-resident weights, rows 5..7 zero, lanes >= 8 re-read row 7); position tile = wave (0..6)
       f32x16 lg;
 #pragma unroll
       for (int i = 0; i < 16; ++i) lg[i] = 0.f;
       if (wave < ntiles) {
-        const char* abase = smem + WB(cur) + lr * ROWB;
-        const int am = (half ^ (lr & 15)) << 4;
+        const int ar = (lr < 7) ? lr : 7;
+        const char* abase = smem + OFF_HEAD2 + ar * ROWB;
+        const int am = (half ^ (ar & 15)) << 4;
         const int p = 32 * wave + lr;
         const int row = (p < L) ? p : ZROW;
         const char* bbase = smem + OFF_HB + row * ROWB;
@@ -392,7 +456,7 @@ __device__ __forceinline__ void sample_body(const SampleArgs& a, char* smem, int
         }
       }
     }
-    END_STAGE();
+    __syncthreads();
 
     // ---- reverse step on this sequence's positions ------------------------------------------
     if (tid < L) {
@@ -429,7 +493,14 @@ __device__ __forceinline__ void sample_body(const SampleArgs& a, char* smem, int
       }
     }
     __syncthreads();
+    ACCUM(3, t0);
   }
+#ifdef DRK_STAMPS
+  if (a.dbg_feat && lane == 0) {
+    unsigned long long* o = (unsigned long long*)a.dbg_feat + (b * 8 + wave) * 4;
+    o[0] = tacc[0]; o[1] = tacc[1]; o[2] = tacc[2]; o[3] = tacc[3];
+  }
+#endif
   if (tid < L) a.x_out[b * L + tid] = tok[tid];
 #undef NEXT_STAGE
 #undef END_STAGE
@@ -439,14 +510,15 @@ __global__ void __launch_bounds__(512, 2) k_sample_bf16(const SampleArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: scalar branches, SGPR tile ids
+  lds_char* lds = (lds_char*)smem;
   if (wave < 4)
-    sample_body<4>(a, smem, tid, wave, lane);
+    sample_body<4>(a, smem, lds, tid, wave, lane);
   else
-    sample_body<3>(a, smem, tid, wave, lane);
+    sample_body<3>(a, smem, lds, tid, wave, lane);
 }
 
 // ------------------------------------------------------------------------------------ C ABI
-extern "C" int drk_sample_bf16(const void* wstream, const float* vecs, const float* tbias, long tb_fwd_stride,
+extern "C" int drk_sample_bf16(const void* wstream, const void* stem_w, const void* head2_w, const float* vecs, const float* tbias, long tb_fwd_stride,
                                const float* mc_table, const float* uniforms, const int64_t* x_init, int64_t* x_out,
                                float* logits_out, int dump_fwd, float* dbg_feat, int dbg_layer, int B, int L, int num_steps, int n_layers,
                                const int* dilations, int noise_removal, uint64_t seed, uint64_t sample_offset,
@@ -456,10 +528,10 @@ extern "C" int drk_sample_bf16(const void* wstream, const float* vecs, const flo
   if (L > MAXPOS) return drk_set_error_msg(DRK_EINVAL, "drk_sample_bf16: L > 224 is not supported by the fused loop");
   if (n_layers < 1 || n_layers > 32 || num_steps < 0 || (num_steps == 0 && !noise_removal))
     return drk_set_error_msg(DRK_EINVAL, "drk_sample_bf16: bad n_layers / num_steps");
-  if (!wstream || !vecs || !tbias || !x_out || !dilations || (num_steps > 0 && !mc_table))
+  if (!wstream || !stem_w || !head2_w || !vecs || !tbias || !x_out || !dilations || (num_steps > 0 && !mc_table))
     return drk_set_error_msg(DRK_EINVAL, "drk_sample_bf16: null pointer");
   SampleArgs a;
-  a.wstream = (const char*)wstream; a.vecs = vecs; a.tbias = tbias; a.tb_fwd_stride = tb_fwd_stride;
+  a.wstream = (const char*)wstream; a.stem_w = (const char*)stem_w; a.head2_w = (const char*)head2_w; a.vecs = vecs; a.tbias = tbias; a.tb_fwd_stride = tb_fwd_stride;
   a.mc_table = mc_table; a.uniforms = uniforms; a.x_init = x_init; a.x_out = x_out; a.logits_out = logits_out;
   a.dump_fwd = dump_fwd; a.dbg_feat = dbg_feat; a.dbg_layer = dbg_layer; a.B = B; a.L = L; a.num_steps = num_steps; a.n_layers = n_layers;
   a.noise_removal = noise_removal ? 1 : 0; a.seed = seed; a.sample_offset = sample_offset;

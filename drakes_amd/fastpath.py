@@ -3,8 +3,9 @@ loop, drakes_amd/csrc/drk_sample_bf16.hip) and launches it.
 
 Weight stream layout (what the kernel's LDS-DMA copies verbatim, stage after stage):
     stage = [128 rows][128 cols] bf16 = 32 KB, 16-byte chunks XOR-swizzled by (row & 15);
-    order = stem (row co, col 5*tap+v), then for each layer its 9 taps (row co, col ci),
-            final_conv.0 (row co, col ci), final_conv.2 (rows 0..4).
+    order = for each layer its 9 taps (row co, col ci), then final_conv.0 (row co, col ci).
+The stem ([128][64] bf16, col 5*tap+v) and final_conv.2 ([8][128] bf16, rows 0..4) are small and stay
+resident in LDS for the whole launch.
 """
 import ctypes
 
@@ -31,10 +32,9 @@ def pack_stream(bb):
     n = bb.num_layers
     with torch.no_grad():
         stages = []
-        stem = torch.zeros(128, 128, device=dev)
-        # linear.weight [co][v][tap] -> col 5*tap + v
+        stem = torch.zeros(128, 64, device=dev)
+        # linear.weight [co][v][tap] -> col 5*tap + v (LDS-resident, plain [128][64] bf16)
         stem[:, :45] = bb.linear.weight.permute(0, 2, 1).reshape(128, 45)
-        stages.append(_swizzle_stage(stem))
         for i in range(n):
             w = bb.convs[i].weight          # [co][ci][tap]
             for t in range(9):
@@ -42,7 +42,6 @@ def pack_stream(bb):
         stages.append(_swizzle_stage(bb.final_conv[0].weight[:, :, 0]))
         head2 = torch.zeros(128, 128, device=dev)
         head2[:ops.V] = bb.final_conv[2].weight[:, :, 0]
-        stages.append(_swizzle_stage(head2))
         # epilogue blocks of 3 vectors: block 0 = stem bias, gamma_0, beta_0; block k+1 = conv bias_k,
         # gamma_{k+1}, beta_{k+1}; last block = conv bias_{n-1}, final_conv.0 bias, final_conv.2 bias (padded)
         hb2 = torch.zeros(128, device=dev)
@@ -55,6 +54,8 @@ def pack_stream(bb):
                 vec_rows += [bb.convs[k].bias, bb.final_conv[0].bias, hb2]
         return {
             'wstream': torch.stack(stages).contiguous(),
+            'stem_w': stem.to(torch.bfloat16).contiguous(),
+            'head2_w': _swizzle_stage(head2)[:8].contiguous(),
             'vecs': torch.stack([v.detach().float() for v in vec_rows]).contiguous(),
             'dil': (ctypes.c_int * n)(*[bb.dilation(i) for i in range(n)]),
             'n_layers': n,
@@ -73,7 +74,7 @@ def _launch(bb, tbias, tb_stride, mc, uniforms, x_init, x_out, logits_out, dump_
             seed, sample_offset, dbg_feat=None, dbg_layer=0):
     pk = _packed(bb)
     P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
-    args = (P(pk['wstream']), P(pk['vecs']), P(tbias), tb_stride, P(mc), P(uniforms), P(x_init), P(x_out),
+    args = (P(pk['wstream']), P(pk['stem_w']), P(pk['head2_w']), P(pk['vecs']), P(tbias), tb_stride, P(mc), P(uniforms), P(x_init), P(x_out),
             P(logits_out), dump_fwd, P(dbg_feat), dbg_layer, B, L, num_steps, pk['n_layers'], pk['dil'], 1 if noise_removal else 0, seed,
             sample_offset, ops._stream())
     flop = 2.0 * B * L * (45 * 128 + pk['n_layers'] * 9 * 128 * 128 + 128 * 128 + 128 * 5) * (num_steps + (1 if noise_removal else 0))

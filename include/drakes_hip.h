@@ -94,7 +94,8 @@ int drk_head_out_fwd(const float* y, const float* w, const float* bias, float* l
 /* The whole of Diffusion._sample (diffusion_gosai_update.py:506-550, ddpm predictor) in one launch:
  * num_steps x (CNNModel.forward + _subs_parameterization + _ddpm_update tail) and, if
  * noise_removal, the final forward + argmax (:541-549).  One workgroup per sequence; L <= 224.
- *   wstream   bf16 weight stages (layout: drakes_amd/fastpath.py::pack_stream)
+ *   wstream   bf16 weight stages: n_layers*9 conv taps + final_conv.0 (layout: drakes_amd/fastpath.py::pack_stream)
+ *   stem_w    bf16 [128][64] stem weights, head2_w bf16 [8][128] final_conv.2 weights (same file)
  *   vecs      float32 [n_layers+1][3][128] biases and LayerNorm affine terms (same file)
  *   tbias     float32 [n_tb][n_layers][128] time biases (drk_time_bias_fwd); forward f reads row
  *             f * tb_fwd_stride / (n_layers*128) (stride 0: time_conditioning=False)
@@ -105,7 +106,7 @@ int drk_head_out_fwd(const float* y, const float* w, const float* bias, float* l
  *   dbg_feat  NULL or float32 [B][L][128]: residual stream of forward dump_fwd after layer
  *             dbg_layer (-1 = after the stem) (tests)
  * num_steps may be 0 with noise_removal=1: one forward + argmax from x_init. */
-int drk_sample_bf16(const void* wstream, const float* vecs, const float* tbias, long tb_fwd_stride,
+int drk_sample_bf16(const void* wstream, const void* stem_w, const void* head2_w, const float* vecs, const float* tbias, long tb_fwd_stride,
                     const float* mc_table, const float* uniforms, const int64_t* x_init, int64_t* x_out,
                     float* logits_out, int dump_fwd, float* dbg_feat, int dbg_layer, int B, int L,
                     int num_steps, int n_layers,
