@@ -5,19 +5,22 @@
 // forwards; sequences never interact, so there is no inter-workgroup traffic.
 //   * the fp32 residual stream lives in REGISTERS, in the MFMA accumulator layout, for the
 //     whole forward; it never touches LDS or HBM;
-//   * the LayerNorm output h (bf16) lives in LDS, XOR-swizzled [position][128 ch], and is the
+//   * the LayerNorm output h (bf16) lives in LDS, [position][128 ch] with padded rows, and is the
 //     B operand of every tap of the dilated convolution: a tap is a row offset into that
 //     image (rows outside [0,L) are redirected to one all-zero row = 'same' zero padding);
-//   * weights (bf16, 5.9 MB for the whole network) stream L2 -> LDS with global_load_lds in
-//     32 KB stages, double-buffered, one stage per tap, pre-swizzled in global memory so the
-//     copy is linear; every CU streams the same bytes at about the same time, so the stream is
-//     L2-resident;
+//   * conv weights (bf16, 5.9 MB for the whole network) are the A operand and go straight from
+//     L2 into registers: they are packed in global memory in MFMA-fragment order, so a wave's
+//     fragment is one contiguous, fully coalesced 1-KB load, and each wave keeps a ring of 8
+//     fragments in flight (one whole tap ahead).  Weights never pass through LDS, so the LDS
+//     carries only activation reads and no barrier is needed inside a layer;
+//     every CU streams the same bytes at about the same time, so the stream stays L2-resident;
 //   * the MFMA is v_mfma_f32_32x32x16_bf16 with A = weights [32 co][16 ci] and
 //     B = activations [16 ci][32 positions]: the accumulator then holds, per lane, ONE position
-//     and 16 channels, which makes the LayerNorm reduction a local sum plus one cross-half
+//     and 16 channels, which makes the LayerNorm reduction a local sum plus one half-wave
 //     exchange plus four partials through LDS, and the h write-back four 8-byte stores;
 //   * stem (one-hot x 45 weights), final_conv.0/.2, SUBS, posterior, Philox, Gumbel-argmax and
-//     carry-over are fused in; per step only the tokens change, and they stay in LDS.
+//     carry-over are fused in; per step only the tokens change, and they stay in LDS; biases,
+//     LayerNorm affine terms and time biases of all layers are LDS-resident.
 // HBM traffic per sequence per step: ~0 (tokens out once at the end).  MFMA-bound.
 //
 // Work split: output tile = 32 channels x 32 positions; 4 channel tiles x 7 position tiles = 28
@@ -29,28 +32,30 @@
 typedef __bf16 bf16v8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16v4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-typedef __attribute__((address_space(3))) char lds_char;   // LDS-typed pointer: LDS-DMA destinations need no generic->LDS cast
 
-#define ROWB 256                 // bytes per LDS image row (128 bf16)
+#define ROWB 272                 // bytes per h-image row: 128 bf16 + 16 B pad.  Row r, 16-B chunk c sits in bank slot
+                                 // (17r + c) mod 16, so 16 consecutive rows read conflict-free at a fixed chunk and a
+                                 // k-step is an IMMEDIATE offset (+32 B) from a per-lane row address: no address VALU
 #define MAXPOS 224               // 7 position tiles
 #define ZROW 224                 // the all-zero row of the h image
-#define STAGE_BYTES 32768        // one weight stage: [128 rows][128 cols] bf16
+#define TAP_BYTES 32768          // one tap of one layer in the fragment stream: [8 k-steps][4 co tiles][64 lanes][16 B]
+#define KSTEP_BYTES 4096
 #define STEM_ROWB 128            // resident stem image: [128 co][64 k] bf16 (k = 5*tap + v, 45 used)
+#define MAX_LAYERS 20
 #define OFF_HB 0
-#define OFF_WB0 (OFF_HB + (ZROW + 1) * ROWB)        // 57600
-#define OFF_WB1 (OFF_WB0 + STAGE_BYTES)
-#define OFF_STEM (OFF_WB1 + STAGE_BYTES)            // resident for the whole launch
-#define OFF_HEAD2 (OFF_STEM + 128 * STEM_ROWB)      // resident: [8 rows][128] bf16, rows 5..7 zero
-#define OFF_PART (OFF_HEAD2 + 8 * ROWB)             // float [2][4][224]: per channel-tile sum, sum of squares
+#define OFF_STEM (OFF_HB + (ZROW + 1) * ROWB)       // 57600
+#define OFF_HEAD2 (OFF_STEM + 128 * STEM_ROWB)      // [8 rows][128] bf16, rows 5..7 zero
+#define OFF_PART (OFF_HEAD2 + 8 * 256)             // float [2][4][224]: per channel-tile sum, sum of squares
 #define OFF_LOG (OFF_PART + 2 * 4 * MAXPOS * 4)     // float [224][8]
 #define OFF_TOK (OFF_LOG + MAXPOS * 8 * 4)          // int [224]
-#define OFF_VEC (OFF_TOK + MAXPOS * 4)              // float [4][128]: the layer's per-channel vectors
-#define LDS_BYTES (OFF_VEC + 4 * 128 * 4)           // 158848 of 163840
+#define OFF_VECS (OFF_TOK + MAXPOS * 4)             // float [n_layers+1][3][128]
+#define OFF_TB (OFF_VECS + (MAX_LAYERS + 1) * 3 * 128 * 4)   // float [n_layers][128]
+#define LDS_BYTES (OFF_TB + MAX_LAYERS * 128 * 4)   // 133760 of 163840
 
 struct SampleArgs {
-  const char* wstream;      // stages, bf16, pre-swizzled: n_layers*9 conv taps, then final_conv.0
+  const char* wfrag;        // conv weights in fragment order: n_layers*9 taps, then final_conv.0 (fastpath.py)
   const char* stem_w;       // [128][64] bf16
-  const char* head2_w;      // [8][128] bf16, chunk-swizzled like a stage
+  const char* head2_w;      // [8][128] bf16, rows 5..7 zero
   const float* vecs;        // [n_layers+1] blocks of [3][128]: block 0 = stem bias, gamma_0, beta_0; block k+1 =
                             // conv bias_k, gamma_{k+1}, beta_{k+1}; the last block = conv bias_{n-1}, head0 bias, head2 bias
   const float* tbias;       // [n_tb][n_layers][128]
@@ -68,35 +73,6 @@ struct SampleArgs {
   uint64_t seed, sample_offset;
 };
 
-// ---- stage streaming -----------------------------------------------------------------------
-__device__ __forceinline__ void prefetch_stage(const char* __restrict__ src, lds_char* lds, int dst_off, int tid, int wave) {
-#pragma unroll
-  for (int it = 0; it < STAGE_BYTES / (512 * 16); ++it) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (it * 512 + tid) * 16),
-                                     (__attribute__((address_space(3))) void*)(lds + dst_off + it * 8192 + wave * 1024),
-                                     16, 0, 0);
-  }
-}
-
-// Per-channel vectors of an epilogue -> LDS: rows 0..2 from a vecs block, row 3 = the time bias of the LayerNorm it
-// feeds.  2 KB = two 1-KB wave instructions (waves 0 and 1); rides on the same vmcnt/barrier as the weight stages.
-__device__ __forceinline__ void prefetch_vecs(const float* __restrict__ vblock, const float* __restrict__ tb, lds_char* lds,
-                                              int wave, int lane) {
-  if (wave == 0) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)vblock + lane * 16),
-                                     (__attribute__((address_space(3))) void*)(lds + OFF_VEC), 16, 0, 0);
-  } else if (wave == 1) {
-    const char* src = (lane < 32) ? ((const char*)vblock + 1024 + lane * 16) : ((const char*)tb + (lane - 32) * 16);
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)(lds + OFF_VEC + 1024), 16, 0, 0);
-  }
-}
-
-__device__ __forceinline__ void stage_sync() {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-}
-
 // Returns `v` through an empty asm: everything derived from the result is recomputed where it is used instead of
 // being hoisted out of the layer/step loops and kept (then spilled) for the whole kernel.
 __device__ __forceinline__ int opaque(int v) {
@@ -104,58 +80,68 @@ __device__ __forceinline__ int opaque(int v) {
   return v;
 }
 
-// ---- one weight stage (= one tap, or a 1x1 conv) --------------------------------------------
-// acc[t] += W_stage[co tile] . h[rows of tile t shifted by `off`], K = 16*KS channels.
-// Fragments of k-step ks+1 are read from LDS while the MFMAs of k-step ks run.
-template <int NT>
-struct Frags {
-  bf16v8 a;
-  bf16v8 b[NT];
-};
-
-template <int KS, int NT>
-__device__ __forceinline__ void mma_stage(const char* smem, int wb_off, int off, int L, int lane, int ct, int grp,
-                                          f32x16 (&acc)[NT]) {
+// ---- one tap (or a 1x1 conv) ----------------------------------------------------------------
+// acc[t] += W_tap[co tile] . h[rows of tile t shifted by `off`], K = 128 channels = 8 k-steps.
+// ring[ks] holds this tap's weight fragments (loaded one tap ago); as each is consumed the SAME ring
+// slot is refilled from `wnext` (this lane's pointer into the next live tap), so 8 global loads
+// (one whole tap, ~2000 cycles) are always in flight.  (A two-tap ring was tried: the second copy of the tap
+// code it needs for static register indexing pushed the allocator into scratch spills, 0.6x.)  Activation fragments of k-step ks+1 are read
+// from LDS while the MFMAs of k-step ks run.
+template <int NT, int TS>
+__device__ __forceinline__ void mma_tap(const char* smem, const char* __restrict__ wnext, bf16v8 (&ring)[8], int off,
+                                        int L, int lane, int grp, f32x16 (&acc)[NT]) {
   const int lo = opaque(lane);
   const int lr = lo & 31, half = lo >> 5;
-  const int arow = 32 * ct + lr;
-  const char* abase = smem + wb_off + arow * ROWB;
-  const int am = (half ^ (arow & 15)) << 4;
-  const char* bbase[NT];
-  int bm[NT];
+  const char* bp[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    const int pp = 32 * (grp + 2 * t) + lr + off;
+    const int pp = 32 * (grp + TS * t) + lr + off;
     const int row = ((unsigned)pp < (unsigned)L) ? pp : ZROW;   // 'same' zero padding = the all-zero row
-    bbase[t] = smem + OFF_HB + row * ROWB;
-    bm[t] = (half ^ (row & 15)) << 4;
+    bp[t] = smem + OFF_HB + row * ROWB + 16 * half;
   }
-  Frags<NT> cur, nxt;
-  cur.a = *(const bf16v8*)(abase + (0 ^ am));
+  bf16v8 cur[NT], nxt[NT];
 #pragma unroll
-  for (int t = 0; t < NT; ++t) cur.b[t] = *(const bf16v8*)(bbase[t] + (0 ^ bm[t]));
-  __builtin_amdgcn_sched_group_barrier(0x100, NT + 1, 0);   // DS reads of k-step 0
+  for (int t = 0; t < NT; ++t) cur[t] = *(const bf16v8*)(bp[t]);
+  __builtin_amdgcn_sched_group_barrier(0x100, NT, 0);   // DS reads of k-step 0
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks) {
-    if (ks + 1 < KS) {
-      nxt.a = *(const bf16v8*)(abase + ((32 * (ks + 1)) ^ am));
+  for (int ks = 0; ks < 8; ++ks) {
+    const bf16v8 a = ring[ks];
+#ifdef DRK_EXP_NOB    // timing experiment: activation fragments read once per tap
+    if (false) {
+#else
+    if (ks + 1 < 8) {
+#endif
 #pragma unroll
-      for (int t = 0; t < NT; ++t) nxt.b[t] = *(const bf16v8*)(bbase[t] + ((32 * (ks + 1)) ^ bm[t]));
+      for (int t = 0; t < NT; ++t) nxt[t] = *(const bf16v8*)(bp[t] + 32 * (ks + 1));
     }
 #pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.a, cur.b[t], acc[t], 0, 0, 0);
-    // Pinned order per k-step: first MFMA (its operand wait covers only reads already a k-step old), then the
-    // next k-step's LDS reads, then the remaining MFMAs, which cover those reads' latency.
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-    if (ks + 1 < KS) __builtin_amdgcn_sched_group_barrier(0x100, NT + 1, 0);
-    if (NT > 1) __builtin_amdgcn_sched_group_barrier(0x008, NT - 1, 0);
-    if (ks + 1 < KS) cur = nxt;
+    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, cur[t], acc[t], 0, 0, 0);
+#ifndef DRK_EXP_NOA   // timing experiment: no weight refill
+    ring[ks] = *(const bf16v8*)(wnext + ks * KSTEP_BYTES);
+#endif
+#if !defined(DRK_EXP_NOA) && !defined(DRK_EXP_NOB)
+    // Pinned order per k-step: MFMA, one LDS read of the next k-step, MFMA, read, ... so that every 32-cycle MFMA
+    // slot carries one read's issue (a burst of NT reads after the first MFMA would stall the in-order wave past the
+    // MFMA it could have issued), each read has a full k-step to land, and the refill of this ring slot comes
+    // AFTER its last reader, so that the MFMAs read the slot in place (no register copy).
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      if (ks + 1 < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+#endif
+#ifndef DRK_EXP_NOB
+    if (ks + 1 < 8) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) cur[t] = nxt[t];
+    }
+#endif
   }
 }
 
-// 16 per-channel values of this lane from LDS vector row `r`: channels 32ct + 8g + 4half + e  <->  register 4g + e.
-__device__ __forceinline__ void load_vec16(const char* smem, int r, int ct, int half, float (&o)[16]) {
-  const float* v = (const float*)(smem + OFF_VEC) + 128 * r;
+// 16 per-channel values of this lane from an LDS vector of 128 floats: channels 32ct + 8g + 4half + e <-> register 4g + e.
+__device__ __forceinline__ void load_vec16(const float* v, int ct, int half, float (&o)[16]) {
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     const f32x4 q = *(const f32x4*)(v + 32 * ct + 8 * g + 4 * half);
@@ -163,7 +149,7 @@ __device__ __forceinline__ void load_vec16(const char* smem, int r, int ct, int 
   }
 }
 
-// Writes 16 channel values of position p as bf16 into the swizzled h image.
+// Writes 16 channel values of position p as bf16 into the h image.
 __device__ __forceinline__ void store_h16(char* smem, int p, int ct, int half, const float (&x)[16]) {
   char* row = smem + OFF_HB + p * ROWB + 8 * half;
 #pragma unroll
@@ -171,25 +157,25 @@ __device__ __forceinline__ void store_h16(char* smem, int p, int ct, int half, c
     bf16v4 pk;
     pk[0] = (__bf16)x[4 * g + 0]; pk[1] = (__bf16)x[4 * g + 1];
     pk[2] = (__bf16)x[4 * g + 2]; pk[3] = (__bf16)x[4 * g + 3];
-    *(bf16v4*)(row + (((4 * ct + g) ^ (p & 15)) << 4)) = pk;
+    *(bf16v4*)(row + ((4 * ct + g) << 4)) = pk;
   }
 }
 
 // Residual update feat += relu(acc + bias) [or feat = relu(acc + bias) after the stem], then, if `do_ln`, the next
 // layer's LayerNorm of (feat + tbias) over the 128 channels of each position -> h image (bf16).
-// Vectors come from the LDS block: row 0 bias, row 1 gamma, row 2 beta, row 3 time bias.
+// blk: vector block [3][128] in LDS (bias, gamma, beta); tbv_src: the LayerNorm's time bias [128] in LDS.
 // A lane holds 16 of a position's 128 channels per tile: local sums, one half-wave exchange (v_permlane32_swap,
-// which leaves sum in the lower and sum-of-squares in the upper half-wave), four partials through LDS.
+// which leaves the sum in the lower and the sum of squares in the upper half-wave), four partials through LDS.
 // Two barriers inside when do_ln; the first also orders "all MFMA reads of the old h image" before its overwrite.
-template <int NT, bool ASSIGN>
-__device__ __forceinline__ void epilogue_ln(char* smem, f32x16 (&feat)[NT], const f32x16 (&acc)[NT], bool do_ln, int L,
-                                            int lane, int ct, int grp) {
+template <int NT, int TS, bool ASSIGN>
+__device__ __forceinline__ void epilogue_ln(char* smem, f32x16 (&feat)[NT], const f32x16 (&acc)[NT], const float* blk,
+                                            const float* tbv_src, bool do_ln, int L, int lane, int ct, int grp) {
 #pragma clang fp contract(fast)
   const int lo = opaque(lane);
   const int lr = lo & 31, half = lo >> 5;
   float cb[16], tbv[16];
-  load_vec16(smem, 0, ct, half, cb);
-  if (do_ln) load_vec16(smem, 3, ct, half, tbv);
+  load_vec16(blk, ct, half, cb);
+  if (do_ln) load_vec16(tbv_src, ct, half, tbv);
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -210,15 +196,15 @@ __device__ __forceinline__ void epilogue_ln(char* smem, f32x16 (&feat)[NT], cons
     }
     const u32x2 sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(s1), __float_as_uint(s2), false, false);
     // lower half-wave: s1(lower) + s1(upper); upper half-wave: s2(lower) + s2(upper)
-    part[(half * 4 + ct) * MAXPOS + 32 * (grp + 2 * t) + lr] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    part[(half * 4 + ct) * MAXPOS + 32 * (grp + TS * t) + lr] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
   }
   float gv[16], bv[16];
-  load_vec16(smem, 1, ct, half, gv);
-  load_vec16(smem, 2, ct, half, bv);
+  load_vec16(blk + 128, ct, half, gv);
+  load_vec16(blk + 256, ct, half, bv);
   __syncthreads();
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    const int p = 32 * (grp + 2 * t) + lr;
+    const int p = 32 * (grp + TS * t) + lr;
     const float s1 = (part[0 * MAXPOS + p] + part[1 * MAXPOS + p]) + (part[2 * MAXPOS + p] + part[3 * MAXPOS + p]);
     const float s2 = (part[4 * MAXPOS + p] + part[5 * MAXPOS + p]) + (part[6 * MAXPOS + p] + part[7 * MAXPOS + p]);
     const float mean = s1 * (1.0f / 128.0f);
@@ -233,12 +219,12 @@ __device__ __forceinline__ void epilogue_ln(char* smem, f32x16 (&feat)[NT], cons
   __syncthreads();
 }
 
-template <int NT>
+template <int NT, int TS>
 __device__ __forceinline__ void dump_feat(float* __restrict__ dst, long b, int L, const f32x16 (&feat)[NT], int lr,
                                           int half, int ct, int grp) {
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    const int p = 32 * (grp + 2 * t) + lr;
+    const int p = 32 * (grp + TS * t) + lr;
     if (p < L) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -249,10 +235,8 @@ __device__ __forceinline__ void dump_feat(float* __restrict__ dst, long b, int L
   }
 }
 
-#define WB(c) ((c) ? OFF_WB1 : OFF_WB0)
-
 // Diagnostic build only (-DDRK_STAMPS, tools/exp.py): per-wave cycle shares of the phases, written to dbg_feat as
-// uint64 [B][8 waves][4] = (mma compute, stage wait+barrier, layer epilogue+LayerNorm, stem/head/step).  Never in the product.
+// uint64 [B][8 waves][4] = (mma, -, layer epilogue+LayerNorm, stem/head/step).  Never in the product.
 #ifdef DRK_STAMPS
 #define STAMP(var)                                         \
   do {                                                     \
@@ -275,8 +259,8 @@ __device__ __forceinline__ void dump_feat(float* __restrict__ dst, long b, int L
 
 // The body, specialised on the number of position tiles this wave owns (4 for waves 0-3, 3 for
 // waves 4-7).  All 7 position tiles are always computed; positions >= L are never stored.
-template <int NT>
-__device__ __forceinline__ void sample_body(const SampleArgs& a, char* smem, lds_char* lds, int tid, int wave, int lane) {
+template <int NT, int TS, int NTHR>
+__device__ __forceinline__ void sample_body(const SampleArgs& a, char* smem, int tid, int wave, int lane) {
   const int lr = lane & 31, half = lane >> 5;
   const int ct = wave & 3, grp = wave >> 2;
   const int L = a.L;
@@ -285,38 +269,43 @@ __device__ __forceinline__ void sample_body(const SampleArgs& a, char* smem, lds
   const uint64_t sample = a.sample_offset + (uint64_t)b;
   int* tok = (int*)(smem + OFF_TOK);
   float* logit = (float*)(smem + OFF_LOG);
+  const float* vecs = (const float*)(smem + OFF_VECS);
+  const float* tbl = (const float*)(smem + OFF_TB);
 
-  // A tap whose shift is >= L reads only padding at every position: its stage is skipped altogether
-  // (no load, no barrier, no MFMA).  Live taps of a layer with dilation d: 4-m .. 4+m, m = min(4, (L-1)/d).
+  // A tap whose shift is >= L reads only padding at every position and is skipped altogether.
+  // Live taps of a layer with dilation d: 4-m .. 4+m, m = min(4, (L-1)/d).
   auto dil_of = [&](int layer) { return (int)((a.dilpk[layer >> 3] >> (8 * (layer & 7))) & 255ull); };
   auto reach_of = [&](int layer) {
     const int d = dil_of(layer);
     const int m = (d > 0) ? (L - 1) / d : 4;
     return m < 4 ? m : 4;
   };
-  const int head0_stage = 9 * a.n_layers;
-  const int first_stage = 4 - reach_of(0);
+  // this lane's pointer to k-step 0 of tap index `tapidx` (= 9*layer + tap; 9*n_layers = final_conv.0)
+  const char* wlane = a.wfrag + ct * 1024 + lane * 16;
+  const int head0_tap = 9 * a.n_layers;
+  const int first_tap = 4 - reach_of(0);
 
-  // ---- init: tokens, zero row, resident stem / final_conv.2 images, first stage ---------------
-  for (int i = tid; i < MAXPOS; i += 512) tok[i] = (i < L) ? (a.x_init ? (int)a.x_init[b * L + i] : DRK_MASK) : DRK_MASK;
-  if (tid < ROWB / 4) ((int*)(smem + OFF_HB + ZROW * ROWB))[tid] = 0;
-  for (int i = tid; i < 128 * STEM_ROWB / 16; i += 512) ((f32x4*)(smem + OFF_STEM))[i] = ((const f32x4*)a.stem_w)[i];
-  if (tid < 8 * ROWB / 16) ((f32x4*)(smem + OFF_HEAD2))[tid] = ((const f32x4*)a.head2_w)[tid];
-  int stage = first_stage;   // index into the weight stream of the stage resident in WB(cur)
-  int cur = 0;
-  prefetch_stage(a.wstream + (long)stage * STAGE_BYTES, lds, OFF_WB0, tid, wave);
-  stage_sync();
-
-#ifdef DRK_EXP_NOSTREAM   // timing experiment only: what the weight stream costs
-#define NEXT_STAGE(nxt) do { (void)(nxt); } while (0)
-#else
-#define NEXT_STAGE(nxt) prefetch_stage(a.wstream + (long)(nxt) * STAGE_BYTES, lds, WB(cur ^ 1), tid, wave)
-#endif
-#define END_STAGE(nxt)  \
-  do {                  \
-    stage_sync();       \
-    stage = (nxt);      \
-    cur ^= 1;           \
+  // ---- init: tokens, zero row, resident weights and vectors, the first tap's fragments --------
+  for (int i = tid; i < MAXPOS; i += NTHR) tok[i] = (i < L) ? (a.x_init ? (int)a.x_init[b * L + i] : DRK_MASK) : DRK_MASK;
+  if (tid < ROWB / 4) ((int*)(smem + OFF_HB + ZROW * ROWB))[tid] = 0;   // the zero row (its pad bytes too)
+  for (int i = tid; i < 128 * STEM_ROWB / 16; i += NTHR) ((f32x4*)(smem + OFF_STEM))[i] = ((const f32x4*)a.stem_w)[i];
+  if (tid < 8 * 256 / 16) ((f32x4*)(smem + OFF_HEAD2))[tid] = ((const f32x4*)a.head2_w)[tid];
+  for (int i = tid; i < (a.n_layers + 1) * 3 * 128 / 4; i += NTHR) ((f32x4*)(smem + OFF_VECS))[i] = ((const f32x4*)a.vecs)[i];
+  // the flat sequence of live taps: ... layer l taps 4-m..4+m, layer l+1 ..., final_conv.0, next forward's first tap ...
+  auto next_tap = [&](int idx) {
+    if (idx == head0_tap) return first_tap;
+    const int layer = idx / 9, tap = idx - 9 * layer;
+    if (tap < 4 + reach_of(layer)) return idx + 1;
+    return (layer + 1 < a.n_layers) ? 9 * (layer + 1) + 4 - reach_of(layer + 1) : head0_tap;
+  };
+  int t_n1 = next_tap(first_tap);   // the tap after the current one: what the current tap refills the ring with
+  bf16v8 ring[8];
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) ring[ks] = *(const bf16v8*)(wlane + (long)first_tap * TAP_BYTES + ks * KSTEP_BYTES);
+#define RUN_TAP(off_)                                                                                   \
+  do {                                                                                                  \
+    mma_tap<NT, TS>(smem, wlane + (long)t_n1 * TAP_BYTES, ring, (off_), L, lane, grp, acc);             \
+    t_n1 = next_tap(t_n1);                                                                              \
   } while (0)
 
 #ifdef DRK_STAMPS
@@ -325,12 +314,14 @@ __device__ __forceinline__ void sample_body(const SampleArgs& a, char* smem, lds
 #endif
   const int n_fwd = a.num_steps + (a.noise_removal ? 1 : 0);
   for (int f = 0; f < n_fwd; ++f) {
-    const float* tb = a.tbias + (long)f * a.tb_fwd_stride;
     f32x16 feat[NT], acc[NT];
+    if (f == 0 || a.tb_fwd_stride != 0) {   // this forward's time biases (all layers) -> LDS
+      const float* tb = a.tbias + (long)f * a.tb_fwd_stride;
+      for (int i = tid; i < a.n_layers * 128 / 4; i += NTHR) ((f32x4*)(smem + OFF_TB))[i] = ((const f32x4*)tb)[i];
+    }
 
     // ---- stem: one-hot(x) [45 -> 48 of K] x W_stem (LDS-resident), as 3 MFMA k-steps ----------
-    // No weight stage is consumed here: the first conv stage of this forward is already resident.
-    prefetch_vecs(a.vecs, tb, lds, wave, lane);
+    __syncthreads();   // tokens / resident tables written above are visible
     {
       const int arow = 32 * ct + lr;
       const char* abase = smem + OFF_STEM + arow * STEM_ROWB + 16 * half;
@@ -338,7 +329,7 @@ __device__ __forceinline__ void sample_body(const SampleArgs& a, char* smem, lds
       for (int t = 0; t < NT; ++t) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-        const int p = 32 * (grp + 2 * t) + lr;
+        const int p = 32 * (grp + TS * t) + lr;
         int nb[9];
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
@@ -362,42 +353,33 @@ __device__ __forceinline__ void sample_body(const SampleArgs& a, char* smem, lds
         }
       }
     }
-    stage_sync();   // the vector block has landed
-    epilogue_ln<NT, true>(smem, feat, acc, true, L, lane, ct, grp);
-    if (a.dbg_feat && f == a.dump_fwd && a.dbg_layer == -1) dump_feat<NT>(a.dbg_feat, b, L, feat, lr, half, ct, grp);
+    epilogue_ln<NT, TS, true>(smem, feat, acc, vecs, tbl, true, L, lane, ct, grp);
+    if (a.dbg_feat && f == a.dump_fwd && a.dbg_layer == -1) dump_feat<NT, TS>(a.dbg_feat, b, L, feat, lr, half, ct, grp);
     ACCUM(3, t0);
 
     // ---- n_layers x (dilated conv + ReLU + residual, then the next layer's LayerNorm) --------
     for (int layer = 0; layer < a.n_layers; ++layer) {
       const int dil = dil_of(layer);
       const int m = reach_of(layer);
-      const int after = (layer + 1 < a.n_layers) ? 9 * (layer + 1) + 4 - reach_of(layer + 1) : head0_stage;
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-      for (int tap = 4 - m; tap <= 4 + m; ++tap) {
-        const int nxt = (tap < 4 + m) ? stage + 1 : after;
-        NEXT_STAGE(nxt);
-        if (tap == 4 - m)   // this layer's epilogue vectors; the previous epilogue is past its last read of them
-          prefetch_vecs(a.vecs + 384 * (layer + 1), tb + 128 * ((layer + 1 < a.n_layers) ? layer + 1 : layer), lds, wave,
-                        lane);
-        mma_stage<8, NT>(smem, WB(cur), (tap - 4) * dil, L, lane, ct, grp, acc);
-        ACCUM(0, t0);
-        END_STAGE(nxt);
-        ACCUM(1, t0);
-      }
-      epilogue_ln<NT, false>(smem, feat, acc, layer + 1 < a.n_layers, L, lane, ct, grp);
-      if (a.dbg_feat && f == a.dump_fwd && a.dbg_layer == layer) dump_feat<NT>(a.dbg_feat, b, L, feat, lr, half, ct, grp);
+      for (int tap = 4 - m; tap <= 4 + m; ++tap) RUN_TAP((tap - 4) * dil);
+      ACCUM(0, t0);
+      epilogue_ln<NT, TS, false>(smem, feat, acc, vecs + 384 * (layer + 1), tbl + 128 * (layer + 1), layer + 1 < a.n_layers,
+                             L, lane, ct, grp);
+      if (a.dbg_feat && f == a.dump_fwd && a.dbg_layer == layer) dump_feat<NT, TS>(a.dbg_feat, b, L, feat, lr, half, ct, grp);
       ACCUM(2, t0);
     }
 
     // ---- head: final_conv.0 (1x1) + ReLU, final_conv.2 (128 -> 5) ---------------------------
+    __syncthreads();   // the last layer did no LayerNorm: every wave is past its reads of the h image
     {
       const int lo_h = opaque(lane);
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        const int p = 32 * (grp + 2 * t) + (lo_h & 31);
+        const int p = 32 * (grp + TS * t) + (lo_h & 31);
         float hv[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) hv[i] = feat[t][i];
@@ -407,18 +389,17 @@ __device__ __forceinline__ void sample_body(const SampleArgs& a, char* smem, lds
       }
     }
     __syncthreads();
-    // the stage after final_conv.0 is the first conv stage of the NEXT forward: its load runs under the head,
-    // the reverse step and the next stem, none of which needs the stream
-    NEXT_STAGE(first_stage);
-    mma_stage<8, NT>(smem, WB(cur), 0, L, lane, ct, grp, acc);
-    END_STAGE(first_stage);   // all reads of the feat image are done
+    // the taps after final_conv.0 are the first conv taps of the NEXT forward: their fragments arrive under the
+    // head, the reverse step and the next stem
+    RUN_TAP(0);
+    __syncthreads();   // all reads of the feat image are done
     {
       const int lo2 = opaque(lane);
       float hb0[16];
-      load_vec16(smem, 1, ct, lo2 >> 5, hb0);
+      load_vec16(vecs + 384 * a.n_layers + 128, ct, lo2 >> 5, hb0);
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        const int p = 32 * (grp + 2 * t) + (lo2 & 31);
+        const int p = 32 * (grp + TS * t) + (lo2 & 31);
         float hv[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) hv[i] = fmaxf(acc[t][i] + hb0[i], 0.f);
@@ -427,25 +408,23 @@ __device__ __forceinline__ void sample_body(const SampleArgs& a, char* smem, lds
     }
     __syncthreads();
     {
-      // 5 output rows (LDS-resident weights, rows 5..7 zero, lanes >= 8 re-read row 7); position tile = wave (0..6)
-      f32x16 lg;
+      // 5 output rows (LDS-resident weights, rows 5..7 zero, lanes >= 8 re-read row 7); position tiles dealt round-robin to waves
+      for (int pt = wave; pt < ntiles; pt += NTHR / 64) {
+        f32x16 lg;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) lg[i] = 0.f;
-      if (wave < ntiles) {
+        for (int i = 0; i < 16; ++i) lg[i] = 0.f;
         const int ar = (lr < 7) ? lr : 7;
-        const char* abase = smem + OFF_HEAD2 + ar * ROWB;
-        const int am = (half ^ (ar & 15)) << 4;
-        const int p = 32 * wave + lr;
+        const char* abase = smem + OFF_HEAD2 + ar * 256 + 16 * half;
+        const int p = 32 * pt + lr;
         const int row = (p < L) ? p : ZROW;
-        const char* bbase = smem + OFF_HB + row * ROWB;
-        const int bm = (half ^ (row & 15)) << 4;
+        const char* bbase = smem + OFF_HB + row * ROWB + 16 * half;
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
-          const bf16v8 av = *(const bf16v8*)(abase + ((32 * ks) ^ am));
-          const bf16v8 bv = *(const bf16v8*)(bbase + ((32 * ks) ^ bm));
+          const bf16v8 av = *(const bf16v8*)(abase + 32 * ks);
+          const bf16v8 bv = *(const bf16v8*)(bbase + 32 * ks);
           lg = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, lg, 0, 0, 0);
         }
-        const float* hb2 = (const float*)(smem + OFF_VEC) + 128 * 2;
+        const float* hb2 = vecs + 384 * a.n_layers + 256;
         if (half == 0) {
           logit[p * 8 + 0] = lg[0] + hb2[0];
           logit[p * 8 + 1] = lg[1] + hb2[1];
@@ -492,30 +471,44 @@ __device__ __forceinline__ void sample_body(const SampleArgs& a, char* smem, lds
         tok[p] = best;
       }
     }
-    __syncthreads();
     ACCUM(3, t0);
   }
+  __syncthreads();
 #ifdef DRK_STAMPS
   if (a.dbg_feat && lane == 0) {
-    unsigned long long* o = (unsigned long long*)a.dbg_feat + (b * 8 + wave) * 4;
+    unsigned long long* o = (unsigned long long*)a.dbg_feat + (b * 8 + wave) * 4;   // [B][8][4] also in the 4-wave build
     o[0] = tacc[0]; o[1] = tacc[1]; o[2] = tacc[2]; o[3] = tacc[3];
   }
 #endif
   if (tid < L) a.x_out[b * L + tid] = tok[tid];
-#undef NEXT_STAGE
-#undef END_STAGE
+#undef RUN_TAP
 }
 
+// Two builds of the same body.  8 waves: two per SIMD, wave w = channel tile (w&3) x position tiles (w>>2)+2t
+// (4 or 3 tiles, 256 registers).  4 waves: one per SIMD, wave w = channel tile w x all 7 position tiles (512
+// registers): every weight fragment is then fetched from L2 by exactly ONE wave per CU (32 KB per tap instead of
+// 64), which is what bounds the 8-wave build (~30 B/clk/CU of L2->register bandwidth).
+#ifndef DRK_WAVES
+#define DRK_WAVES 4
+#endif
+#if DRK_WAVES == 8
 __global__ void __launch_bounds__(512, 2) k_sample_bf16(const SampleArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: scalar branches, SGPR tile ids
-  lds_char* lds = (lds_char*)smem;
   if (wave < 4)
-    sample_body<4>(a, smem, lds, tid, wave, lane);
+    sample_body<4, 2, 512>(a, smem, tid, wave, lane);
   else
-    sample_body<3>(a, smem, lds, tid, wave, lane);
+    sample_body<3, 2, 512>(a, smem, tid, wave, lane);
 }
+#else
+__global__ void __launch_bounds__(256, 1) k_sample_bf16(const SampleArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  sample_body<7, 1, 256>(a, smem, tid, wave, lane);
+}
+#endif
 
 // ------------------------------------------------------------------------------------ C ABI
 extern "C" int drk_sample_bf16(const void* wstream, const void* stem_w, const void* head2_w, const float* vecs, const float* tbias, long tb_fwd_stride,
@@ -526,12 +519,12 @@ extern "C" int drk_sample_bf16(const void* wstream, const void* stem_w, const vo
   if (B < 0 || L <= 0) return drk_set_error_msg(DRK_EINVAL, "drk_sample_bf16: bad shape");
   if (B == 0) return DRK_OK;
   if (L > MAXPOS) return drk_set_error_msg(DRK_EINVAL, "drk_sample_bf16: L > 224 is not supported by the fused loop");
-  if (n_layers < 1 || n_layers > 32 || num_steps < 0 || (num_steps == 0 && !noise_removal))
+  if (n_layers < 1 || n_layers > MAX_LAYERS || num_steps < 0 || (num_steps == 0 && !noise_removal))
     return drk_set_error_msg(DRK_EINVAL, "drk_sample_bf16: bad n_layers / num_steps");
   if (!wstream || !stem_w || !head2_w || !vecs || !tbias || !x_out || !dilations || (num_steps > 0 && !mc_table))
     return drk_set_error_msg(DRK_EINVAL, "drk_sample_bf16: null pointer");
   SampleArgs a;
-  a.wstream = (const char*)wstream; a.stem_w = (const char*)stem_w; a.head2_w = (const char*)head2_w; a.vecs = vecs; a.tbias = tbias; a.tb_fwd_stride = tb_fwd_stride;
+  a.wfrag = (const char*)wstream; a.stem_w = (const char*)stem_w; a.head2_w = (const char*)head2_w; a.vecs = vecs; a.tbias = tbias; a.tb_fwd_stride = tb_fwd_stride;
   a.mc_table = mc_table; a.uniforms = uniforms; a.x_init = x_init; a.x_out = x_out; a.logits_out = logits_out;
   a.dump_fwd = dump_fwd; a.dbg_feat = dbg_feat; a.dbg_layer = dbg_layer; a.B = B; a.L = L; a.num_steps = num_steps; a.n_layers = n_layers;
   a.noise_removal = noise_removal ? 1 : 0; a.seed = seed; a.sample_offset = sample_offset;
@@ -544,7 +537,7 @@ extern "C" int drk_sample_bf16(const void* wstream, const void* stem_w, const vo
     hipError_t e = hipFuncSetAttribute((const void*)k_sample_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e != hipSuccess) return drk_set_error(e, "drk_sample_bf16(hipFuncSetAttribute)");
   }
-  hipLaunchKernelGGL(k_sample_bf16, dim3(B), dim3(512), LDS_BYTES, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(k_sample_bf16, dim3(B), dim3(64 * DRK_WAVES), LDS_BYTES, (hipStream_t)stream, a);
   DRK_CHECK_LAUNCH();
   return DRK_OK;
 }

@@ -1,9 +1,9 @@
 """Host side of the bf16 fast path: packs the denoiser for drk_sample_bf16 (the fused sampling
 loop, drakes_amd/csrc/drk_sample_bf16.hip) and launches it.
 
-Weight stream layout (what the kernel's LDS-DMA copies verbatim, stage after stage):
-    stage = [128 rows][128 cols] bf16 = 32 KB, 16-byte chunks XOR-swizzled by (row & 15);
-    order = for each layer its 9 taps (row co, col ci), then final_conv.0 (row co, col ci).
+Weight stream layout (MFMA-fragment order, read straight from L2 into registers):
+    tap = [8 k-steps][4 co tiles][64 lanes][8 bf16] = 32 KB (see _frag_tap);
+    order = for each layer its 9 taps, then final_conv.0.
 The stem ([128][64] bf16, col 5*tap+v) and final_conv.2 ([8][128] bf16, rows 0..4) are small and stay
 resident in LDS for the whole launch.
 """
@@ -14,6 +14,13 @@ import torch
 from . import _lib, ops
 
 MAX_L = 224
+
+
+def _frag_tap(m):
+    """[128 co][128 ci] float -> bf16 [8 k-steps][4 co tiles][64 lanes][8]: lane (lr, half) of the wave that owns
+    co tile ct holds, for k-step ks, W[32ct + lr][16ks + 8half + 0..7] (the A operand of v_mfma_f32_32x32x16_bf16)."""
+    w = m.to(torch.bfloat16).reshape(4, 32, 8, 2, 8)      # [ct][lr][ks][half][j]
+    return w.permute(2, 0, 3, 1, 4).contiguous().reshape(8, 4, 64, 8)
 
 
 def _swizzle_stage(m):
@@ -38,8 +45,8 @@ def pack_stream(bb):
         for i in range(n):
             w = bb.convs[i].weight          # [co][ci][tap]
             for t in range(9):
-                stages.append(_swizzle_stage(w[:, :, t]))
-        stages.append(_swizzle_stage(bb.final_conv[0].weight[:, :, 0]))
+                stages.append(_frag_tap(w[:, :, t]))
+        stages.append(_frag_tap(bb.final_conv[0].weight[:, :, 0]))
         head2 = torch.zeros(128, 128, device=dev)
         head2[:ops.V] = bb.final_conv[2].weight[:, :, 0]
         # epilogue blocks of 3 vectors: block 0 = stem bias, gamma_0, beta_0; block k+1 = conv bias_k,
@@ -55,7 +62,7 @@ def pack_stream(bb):
         return {
             'wstream': torch.stack(stages).contiguous(),
             'stem_w': stem.to(torch.bfloat16).contiguous(),
-            'head2_w': _swizzle_stage(head2)[:8].contiguous(),
+            'head2_w': head2[:8].to(torch.bfloat16).contiguous(),
             'vecs': torch.stack([v.detach().float() for v in vec_rows]).contiguous(),
             'dil': (ctypes.c_int * n)(*[bb.dilation(i) for i in range(n)]),
             'n_layers': n,
