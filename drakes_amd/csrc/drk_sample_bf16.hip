@@ -489,7 +489,7 @@ __device__ __forceinline__ void sample_body(const SampleArgs& a, char* smem, int
 // registers): every weight fragment is then fetched from L2 by exactly ONE wave per CU (32 KB per tap instead of
 // 64), which is what bounds the 8-wave build (~30 B/clk/CU of L2->register bandwidth).
 #ifndef DRK_WAVES
-#define DRK_WAVES 4
+#define DRK_WAVES 8
 #endif
 #if DRK_WAVES == 8
 __global__ void __launch_bounds__(512, 2) k_sample_bf16(const SampleArgs a) {
