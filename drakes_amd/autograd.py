@@ -1,0 +1,165 @@
+"""torch.autograd glue over the HIP forward/backward kernels.
+
+The reference differentiates CNNModel.forward, _subs_parameterization and the Gumbel-softmax
+reverse step with torch autograd (diffusion_gosai_update.py:552-630; fine_tune,
+finetune_reward_bp.py:60-93).  Here every differentiable block is ONE autograd.Function whose
+forward and backward are chains of calls into libdrakes_hip.so; torch only owns the buffers and
+the graph.  What is saved per denoiser forward: the 21 residual-stream snapshots, the LayerNorm
+statistics, the uint8 ReLU masks and final_conv.0's output (the LayerNorm output h is recomputed
+in the backward pass).
+"""
+import torch
+
+from . import ops
+
+C, V = ops.C, ops.V
+
+
+def _zeros(*shape, like):
+    return torch.zeros(*shape, dtype=torch.float32, device=like.device)
+
+
+class _BackboneFn(torch.autograd.Function):
+    """logits = CNNModel(seq, sigma).  sigma has one element per batch row, or ONE element shared by
+    the whole batch (the sampler's case: all rows sit at the same time, :527-528)."""
+
+    @staticmethod
+    def forward(ctx, bb, seq, sigma, *params):
+        pk = bb.packed()
+        seq = seq.contiguous()
+        B, L = seq.shape[0], seq.shape[1]
+        n = bb.num_layers
+        sigma = sigma.to(torch.float32).contiguous()
+        nb = sigma.shape[0]
+        assert nb in (1, B), 'sigma: one value per row or one shared value'
+        temb = ops.time_embed_fwd(sigma, pk['four_W'], pk['temb_w'], pk['temb_b'])
+        tbias = ops.time_bias_fwd(temb, pk['dense_w'], pk['dense_b'])
+        tb_stride = tbias.stride(0) if nb == B and B > 1 else 0
+        feats = [ops.stem_fwd(seq, pk['stem_w'], pk['stem_b'])]
+        means, rstds, masks = [], [], []
+        h = torch.empty(B, L, C, dtype=torch.float32, device=seq.device)
+        for i in range(n):
+            mean = torch.empty(B * L, dtype=torch.float32, device=seq.device)
+            rstd = torch.empty_like(mean)
+            ops.ln_fwd(feats[i], tbias[0, i], tb_stride, pk['ln_g'][i], pk['ln_b'][i], out=h, mean=mean, rstd=rstd)
+            mask = torch.empty(B, L, C, dtype=torch.uint8, device=seq.device)
+            feats.append(ops.conv_fwd_f32(h, pk['conv_w'][i], pk['conv_b'][i], feats[i], bb.dilation(i), relu=True,
+                                          relu_mask=mask))
+            means.append(mean), rstds.append(rstd), masks.append(mask)
+        y = ops.conv_fwd_f32(feats[n], pk['head0_w'], pk['head0_b'], None, 0, relu=True)
+        logits = ops.head_out_fwd(y, pk['head2_w'], pk['head2_b'])
+        ctx.bb, ctx.pk, ctx.seq, ctx.sigma, ctx.temb, ctx.tbias, ctx.tb_stride = bb, pk, seq, sigma, temb, tbias, tb_stride
+        ctx.feats, ctx.means, ctx.rstds, ctx.masks, ctx.y = feats, means, rstds, masks, y
+        ctx.names = [k for k, _ in bb.named_parameters()]
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        bb, pk, seq = ctx.bb, ctx.pk, ctx.seq
+        feats, means, rstds, masks, y = ctx.feats, ctx.means, ctx.rstds, ctx.masks, ctx.y
+        B, L = seq.shape[0], seq.shape[1]
+        M, n = B * L, bb.num_layers
+        nb = ctx.sigma.shape[0]
+        dlogits = dlogits.contiguous()
+        g = {}
+        # head
+        dy = torch.empty_like(y)
+        dw2, db2 = _zeros(V, C, like=y), _zeros(V, like=y)
+        ops.head_out_bwd(dlogits, y, pk['head2_w'], dy, dw2, db2)
+        dpre = ops.relu_bwd(dy, y, out=dy)
+        dw0 = _zeros(1, C, C, like=y)
+        ops.conv_wgrad_f32(feats[n], dpre, dw0, 0)
+        db0 = ops.colsum128(dpre, 1, M, _zeros(1, C, like=y))
+        gr = ops.conv_fwd_f32(dpre, pk['head0_wT'], None, None, 0, relu=False)
+        g['final_conv.2.weight'], g['final_conv.2.bias'] = dw2.unsqueeze(-1), db2
+        g['final_conv.0.weight'], g['final_conv.0.bias'] = dw0.permute(2, 1, 0), db0[0]
+        # layers
+        dtb = _zeros(n, nb, C, like=y)
+        h = torch.empty_like(y)
+        dc = torch.empty_like(y)
+        dh = torch.empty_like(y)
+        dxin = torch.empty_like(y)
+        for i in reversed(range(n)):
+            d = bb.dilation(i)
+            ops.mask_mul(gr, masks[i], out=dc)
+            g[f'convs.{i}.bias'] = ops.colsum128(dc, 1, M, _zeros(1, C, like=y))[0]
+            ops.ln_fwd(feats[i], ctx.tbias[0, i], ctx.tb_stride, pk['ln_g'][i], pk['ln_b'][i], out=h)
+            dwt = _zeros(9, C, C, like=y)
+            ops.conv_wgrad_f32(h, dc, dwt, d)
+            g[f'convs.{i}.weight'] = dwt.permute(2, 1, 0)
+            ops.conv_fwd_f32(dc, pk['conv_wT'][i], None, None, d, relu=False, out=dh)
+            dgam, dbet = _zeros(C, like=y), _zeros(C, like=y)
+            gnew = torch.empty_like(y)
+            ops.ln_bwd(dh, feats[i], ctx.tbias[0, i], ctx.tb_stride, pk['ln_g'][i], means[i], rstds[i], gr, dxin, gnew,
+                       dgam, dbet)
+            g[f'norms.{i}.weight'], g[f'norms.{i}.bias'] = dgam, dbet
+            if ctx.tb_stride:
+                ops.colsum128(dxin, B, L, dtb[i])
+            else:
+                ops.colsum128(dxin, 1, M, dtb[i])
+            gr = gnew
+        # stem
+        dpre = ops.relu_bwd(gr, feats[0], out=gr)
+        g['linear.bias'] = ops.colsum128(dpre, 1, M, _zeros(1, C, like=y))[0]
+        dw_t = _zeros(9, V, C, like=y)
+        dseq = None
+        if seq.dtype != torch.int64:
+            dseq = torch.empty_like(seq)
+        ops.stem_bwd(dpre, seq, pk['stem_w'], dw_t, dseq)
+        g['linear.weight'] = dw_t.permute(2, 1, 0)
+        # time path
+        d_dense_w, d_dense_b = _zeros(n, C, C, like=y), _zeros(n, C, like=y)
+        d_lin_w, d_lin_b = _zeros(C, C, like=y), _zeros(C, like=y)
+        ops.time_bwd(dtb.permute(1, 0, 2).contiguous(), ctx.sigma, pk['four_W'], ctx.temb, pk['dense_w'], d_dense_w,
+                     d_dense_b, d_lin_w, d_lin_b)
+        g['time_embedder.1.weight'], g['time_embedder.1.bias'] = d_lin_w, d_lin_b
+        for i in range(n):
+            g[f'time_layers.{i}.dense.weight'], g[f'time_layers.{i}.dense.bias'] = d_dense_w[i], d_dense_b[i]
+        grads = [g.get(k) if ctx.needs_input_grad[3 + j] else None for j, k in enumerate(ctx.names)]
+        ctx.feats = ctx.masks = ctx.means = ctx.rstds = ctx.y = None
+        return (None, dseq if ctx.needs_input_grad[1] else None, None, *grads)
+
+
+def backbone_with_grad(bb, seq, sigma):
+    return _BackboneFn.apply(bb, seq, sigma, *bb.parameters())
+
+
+class _SubsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, xt):
+        ctx.save_for_backward(logits, xt)
+        return ops.subs_fwd(logits.contiguous(), xt.contiguous())
+
+    @staticmethod
+    def backward(ctx, dlogp):
+        logits, xt = ctx.saved_tensors
+        return ops.subs_bwd(logits.contiguous(), xt.contiguous(), dlogp.contiguous()), None
+
+
+def subs_with_grad(logits, xt):
+    return _SubsFn.apply(logits, xt)
+
+
+class _SoftStepFn(torch.autograd.Function):
+    """(x_next, soft_copy_flag) = soft reverse step(logits, x_soft); noise is recomputed in the backward."""
+
+    @staticmethod
+    def forward(ctx, logits, x_soft, mc_t, mc_s, temp, cft, seed, step, sample_offset, uniforms):
+        logits, x_soft = logits.contiguous(), x_soft.contiguous()
+        x_next, flag = ops.reverse_step_soft_fwd(logits, x_soft, mc_t, mc_s, temp, cft, seed, step, sample_offset, uniforms)
+        ctx.save_for_backward(logits, x_soft)
+        ctx.consts = (mc_t, mc_s, temp, cft, seed, step, sample_offset, uniforms)
+        return x_next, flag.unsqueeze(-1)
+
+    @staticmethod
+    def backward(ctx, g_next, g_flag):
+        logits, x_soft = ctx.saved_tensors
+        mc_t, mc_s, temp, cft, seed, step, sample_offset, uniforms = ctx.consts
+        gf = g_flag.reshape(g_flag.shape[0], g_flag.shape[1]).contiguous() if g_flag is not None else None
+        dlogits, dx = ops.reverse_step_soft_bwd(logits, x_soft, g_next.contiguous(), gf, mc_t, mc_s, temp, cft, seed, step,
+                                                sample_offset, uniforms)
+        return dlogits, dx, None, None, None, None, None, None, None, None
+
+
+def soft_step_with_grad(logits, x_soft, mc_t, mc_s, temp, cft, seed, step, sample_offset, uniforms):
+    return _SoftStepFn.apply(logits, x_soft, mc_t, mc_s, temp, cft, seed, step, sample_offset, uniforms)

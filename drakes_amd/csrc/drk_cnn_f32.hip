@@ -121,7 +121,8 @@ __global__ void __launch_bounds__(256) k_ln_fwd(const float* __restrict__ feat, 
 template <int MT>
 __global__ void __launch_bounds__(256) k_conv_f32(const float* __restrict__ h, const float* __restrict__ w_pk,
                                                   const float* __restrict__ bias, const float* resid, float* out,
-                                                  long M, int L, int taps, int dil, int relu) {
+                                                  unsigned char* __restrict__ relu_mask, long M, int L, int taps, int dil,
+                                                  int relu) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int half = lane >> 5, lr = lane & 31;
   const long r0 = (long)blockIdx.x * (32 * MT);
@@ -164,7 +165,7 @@ __global__ void __launch_bounds__(256) k_conv_f32(const float* __restrict__ h, c
           acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][j], b[j], acc[mt], 0, 0, 0);
     }
   }
-  const float bco = bias[co];
+  const float bco = bias ? bias[co] : 0.0f;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -172,6 +173,7 @@ __global__ void __launch_bounds__(256) k_conv_f32(const float* __restrict__ h, c
       const long row = r0 + 32 * mt + (i & 3) + 8 * (i >> 2) + 4 * half;
       if (row < M) {
         float v = acc[mt][i] + bco;
+        if (relu_mask) relu_mask[row * DRK_C + co] = v > 0.0f ? 1 : 0;   // kept for the backward pass
         if (relu) v = fmaxf(v, 0.0f);
         if (resid) v += resid[row * DRK_C + co];
         out[row * DRK_C + co] = v;
@@ -265,14 +267,13 @@ extern "C" int drk_ln_fwd(const float* feat, const float* tbias, long tbias_bstr
 }
 
 extern "C" int drk_conv_fwd_f32(const float* h, const float* w_pk, const float* bias, const float* resid, float* out,
-                                int B, int L, int taps, int dilation, int relu, void* stream) {
+                                unsigned char* relu_mask, int B, int L, int taps, int dilation, int relu, void* stream) {
   DRK_SHAPE_GUARD("drk_conv_fwd_f32");
-  ARGCHECK(h && w_pk && bias && out && B >= 0 && L > 0 && taps >= 1 && (taps & 1) && dilation >= 0,
-           "drk_conv_fwd_f32");
+  ARGCHECK(h && w_pk && out && B >= 0 && L > 0 && taps >= 1 && (taps & 1) && dilation >= 0, "drk_conv_fwd_f32");
   const long M = (long)B * L;
   if (M == 0) return DRK_OK;
   hipLaunchKernelGGL(k_conv_f32<2>, dim3((unsigned)((M + 63) / 64)), dim3(256), 0, (hipStream_t)stream, h, w_pk, bias,
-                     resid, out, M, L, taps, dilation, relu);
+                     resid, out, relu_mask, M, L, taps, dilation, relu);
   DRK_CHECK_LAUNCH();
   return DRK_OK;
 }

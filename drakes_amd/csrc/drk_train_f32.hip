@@ -1,0 +1,588 @@
+// Backward kernels of the fp32 denoiser and of the soft (Gumbel-softmax) reverse step, for the
+// truncated reward backpropagation of Diffusion._sample_finetune_gradient
+// (diffusion_gosai_update.py:552-630) and the KL loop of fine_tune (finetune_reward_bp.py:60-75).
+// The reference gets all of this from torch autograd; here each backward op is a kernel and
+// drakes_amd/autograd.py chains them.  Parameter gradients are ACCUMULATED with fp32 atomics into
+// buffers the caller zeroes (float atomic sums depend on arrival order: last-bit differences
+// between runs are expected and covered by the stated gradient tolerance).
+#include "drk_common.h"
+#include "../../include/drakes_hip.h"
+
+#define ARGCHECK(cond, name) \
+  if (!(cond)) return drk_set_error_msg(DRK_EINVAL, name ": bad arguments")
+
+static inline int grid_for(long n, int per_block) {
+  long g = (n + per_block - 1) / per_block;
+  if (g > 4096) g = 4096;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+// ------------------------------------------------------------------------------------ elementwise
+// out = g * mask   (mask: uint8 0/1 written by drk_conv_fwd_f32)      -- ReLU backward
+__global__ void __launch_bounds__(256) k_mask_mul(const float* __restrict__ g, const unsigned char* __restrict__ mask,
+                                                  float* __restrict__ out, long n4) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const f32x4 v = ((const f32x4*)g)[i];
+    const uchar4 m = ((const uchar4*)mask)[i];
+    ((f32x4*)out)[i] = f32x4{m.x ? v[0] : 0.f, m.y ? v[1] : 0.f, m.z ? v[2] : 0.f, m.w ? v[3] : 0.f};
+  }
+}
+// out = g * (y > 0)   (y: a saved ReLU OUTPUT)
+__global__ void __launch_bounds__(256) k_relu_bwd(const float* __restrict__ g, const float* __restrict__ y,
+                                                  float* __restrict__ out, long n4) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const f32x4 v = ((const f32x4*)g)[i], yy = ((const f32x4*)y)[i];
+    ((f32x4*)out)[i] = f32x4{yy[0] > 0.f ? v[0] : 0.f, yy[1] > 0.f ? v[1] : 0.f, yy[2] > 0.f ? v[2] : 0.f,
+                             yy[3] > 0.f ? v[3] : 0.f};
+  }
+}
+
+// ------------------------------------------------------------------------------------ column sums
+// out[seg][c] += sum over the rows of segment seg of x[row][c];  rows = nseg * seg_rows, 128 columns.
+// Workgroup = 256 threads = 2 row-phases x 128 columns over a block of 64 rows of one segment.
+__global__ void __launch_bounds__(256) k_colsum128(const float* __restrict__ x, float* __restrict__ out, long seg_rows) {
+  __shared__ float red[128];
+  const int c = threadIdx.x & 127, ph = threadIdx.x >> 7;
+  const long seg = blockIdx.y;
+  const long r0 = (long)blockIdx.x * 64;
+  float s = 0.f;
+  for (long r = r0 + ph; r < r0 + 64 && r < seg_rows; r += 2) s += x[(seg * seg_rows + r) * DRK_C + c];
+  if (ph == 1) red[c] = s;
+  __syncthreads();
+  if (ph == 0) atomicAdd(out + seg * DRK_C + c, s + red[c]);
+}
+
+// ------------------------------------------------------------------------------------ LayerNorm backward
+// Forward: xin = feat + tbias; xhat = (xin - mean) * rstd; h = xhat * gamma + beta.
+// Given dh: dxin = rstd * (dyg - mean_c(dyg) - xhat * mean_c(dyg * xhat)),  dyg = dh * gamma;
+//           dgamma += sum_rows dh * xhat;  dbeta += sum_rows dh.
+// dfeat_out = dxin + g_resid (the gradient arriving through the residual branch); dxin is also stored
+// on its own for the time-bias gradient.  32 lanes per row; per-workgroup partial column sums in LDS,
+// then one atomic per column per workgroup.
+__global__ void __launch_bounds__(256) k_ln_bwd(const float* __restrict__ dh, const float* __restrict__ feat,
+                                                const float* __restrict__ tbias, long tb_stride,
+                                                const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                const float* __restrict__ rstd, const float* __restrict__ g_resid,
+                                                float* __restrict__ dxin, float* __restrict__ dfeat,
+                                                float* __restrict__ dgamma, float* __restrict__ dbeta, long M, int L) {
+  __shared__ float pg[8][128], pb[8][128];
+  const int lr = threadIdx.x & 31, sub = threadIdx.x >> 5;
+  const f32x4 gm = *(const f32x4*)(gamma + 4 * lr);
+  f32x4 ag = {0.f, 0.f, 0.f, 0.f}, ab = {0.f, 0.f, 0.f, 0.f};
+  for (long row = (long)blockIdx.x * 64 + sub; row < (long)blockIdx.x * 64 + 64 && row < M; row += 8) {
+    const long b = row / L;
+    f32x4 x = *(const f32x4*)(feat + row * DRK_C + 4 * lr);
+    if (tbias) x += *(const f32x4*)(tbias + b * tb_stride + 4 * lr);
+    const float mu = mean[row], rs = rstd[row];
+    const f32x4 xh = (x - mu) * rs;
+    const f32x4 d = *(const f32x4*)(dh + row * DRK_C + 4 * lr);
+    const f32x4 dyg = d * gm;
+    float s1 = (dyg[0] + dyg[1]) + (dyg[2] + dyg[3]);
+    float s2 = (dyg[0] * xh[0] + dyg[1] * xh[1]) + (dyg[2] * xh[2] + dyg[3] * xh[3]);
+#pragma unroll
+    for (int o = 16; o >= 1; o >>= 1) {
+      s1 += __shfl_xor(s1, o);
+      s2 += __shfl_xor(s2, o);
+    }
+    const float m1 = s1 * (1.0f / DRK_C), m2 = s2 * (1.0f / DRK_C);
+    const f32x4 dx = (dyg - m1 - xh * m2) * rs;
+    *(f32x4*)(dxin + row * DRK_C + 4 * lr) = dx;
+    f32x4 o = dx;
+    if (g_resid) o += *(const f32x4*)(g_resid + row * DRK_C + 4 * lr);
+    *(f32x4*)(dfeat + row * DRK_C + 4 * lr) = o;
+    ag += d * xh;
+    ab += d;
+  }
+  *(f32x4*)(&pg[sub][4 * lr]) = ag;
+  *(f32x4*)(&pb[sub][4 * lr]) = ab;
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    float sg = 0.f, sb = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      sg += pg[k][threadIdx.x];
+      sb += pb[k][threadIdx.x];
+    }
+    atomicAdd(dgamma + threadIdx.x, sg);
+    atomicAdd(dbeta + threadIdx.x, sb);
+  }
+}
+
+// ------------------------------------------------------------------------------------ conv weight gradient
+// dwt[t][ci][co] += sum_rows h[row + off_t][ci] * dc[row][co]     (rows whose shifted position leaves [0,L) add 0)
+// GEMM with K = rows on the f32-input MFMA: A = h^T [32 ci x 2 rows], B = dc [2 rows x 32 co]; both operands are
+// row-contiguous, so every wave-load is two dense 128-byte spans.  Workgroup = (row chunk, tap); wave w = ci tile w,
+// all four co tiles.  Partial 128x128 tiles are added with fp32 atomics, 32 consecutive co per half-wave.
+#define WG_ROWS 512
+__global__ void __launch_bounds__(256) k_conv_wgrad(const float* __restrict__ h, const float* __restrict__ dc,
+                                                    float* __restrict__ dwt, long M, int L, int taps, int dil) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int half = lane >> 5, lr = lane & 31;
+  const int t = blockIdx.y;
+  const int off = (t - taps / 2) * dil;
+  const long r0 = (long)blockIdx.x * WG_ROWS;
+  f32x16 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+  for (int s = 0; s < WG_ROWS / 2; ++s) {
+    const long row = r0 + 2 * s + half;
+    if (r0 + 2 * s >= M) break;
+    float a = 0.f;
+    f32x4 bq = {0.f, 0.f, 0.f, 0.f};
+    if (row < M) {
+      const int p = (int)(row % L) + off;
+      if (p >= 0 && p < L) a = h[(row + off) * DRK_C + 32 * w + lr];
+      const float* d = dc + row * DRK_C + lr;
+      bq = f32x4{d[0], d[32], d[64], d[96]};
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq[j], acc[j], 0, 0, 0);
+  }
+  float* dst = dwt + (long)t * DRK_C * DRK_C;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int ci = 32 * w + (i & 3) + 8 * (i >> 2) + 4 * half;
+      atomicAdd(dst + ci * DRK_C + 32 * j + lr, acc[j][i]);
+    }
+}
+
+// ------------------------------------------------------------------------------------ head (128 -> 5) backward
+// dy[row][c] = sum_v dlogits[row][v] * w[v][c];  dw[v][c] += sum_rows dlogits[row][v] * y[row][c];  db[v] += sum_rows dlogits
+__global__ void __launch_bounds__(256) k_head_out_bwd(const float* __restrict__ dlogits, const float* __restrict__ y,
+                                                      const float* __restrict__ w, float* __restrict__ dy,
+                                                      float* __restrict__ dw, float* __restrict__ db, long M) {
+  __shared__ float ws[DRK_V * DRK_C];
+  __shared__ float pw[2][DRK_V][DRK_C];
+  for (int i = threadIdx.x; i < DRK_V * DRK_C; i += 256) ws[i] = w[i];
+  __syncthreads();
+  const int c = threadIdx.x & 127, ph = threadIdx.x >> 7;
+  float aw[DRK_V] = {0.f, 0.f, 0.f, 0.f, 0.f}, ab[DRK_V] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  for (long row = (long)blockIdx.x * 64 + ph; row < (long)blockIdx.x * 64 + 64 && row < M; row += 2) {
+    float dl[DRK_V];
+#pragma unroll
+    for (int v = 0; v < DRK_V; ++v) dl[v] = dlogits[row * DRK_V + v];
+    const float yy = y[row * DRK_C + c];
+    float o = 0.f;
+#pragma unroll
+    for (int v = 0; v < DRK_V; ++v) {
+      o += dl[v] * ws[v * DRK_C + c];
+      aw[v] += dl[v] * yy;
+      ab[v] += dl[v];
+    }
+    dy[row * DRK_C + c] = o;
+  }
+#pragma unroll
+  for (int v = 0; v < DRK_V; ++v) pw[ph][v][c] = aw[v];
+  __syncthreads();
+  if (ph == 0) {
+#pragma unroll
+    for (int v = 0; v < DRK_V; ++v) atomicAdd(dw + v * DRK_C + c, pw[0][v][c] + pw[1][v][c]);
+  }
+  if (c == 0) {
+#pragma unroll
+    for (int v = 0; v < DRK_V; ++v) atomicAdd(db + v, ab[v]);
+  }
+}
+
+// ------------------------------------------------------------------------------------ stem backward
+// dpre[row][co] = dfeat0[row][co] * (feat0 > 0) is formed by the caller (k_relu_bwd).
+// dw_t[t][v][co] += sum_rows dpre[row][co] * xs[row + t - 4][v];   db via k_colsum128;
+// dx[row][v] = sum_t sum_co dpre[row - (t-4)][co] * w_t[t][v][co]   (soft input only).
+__global__ void __launch_bounds__(256) k_stem_wgrad(const float* __restrict__ dpre, const int64_t* __restrict__ x,
+                                                    const float* __restrict__ x_soft, float* __restrict__ dw_t, long M,
+                                                    int L) {
+  __shared__ float xs[(64 + 8) * DRK_V];
+  __shared__ float pw[2][DRK_TAPS * DRK_V][DRK_C];   // 46 KB
+  const long r0 = (long)blockIdx.x * 64;
+  for (int i = threadIdx.x; i < (64 + 8) * DRK_V; i += 256) {
+    const long r = r0 - 4 + i / DRK_V;
+    const int v = i % DRK_V;
+    float val = 0.f;
+    if (r >= 0 && r < M) val = x ? ((int)x[r] == v ? 1.f : 0.f) : x_soft[r * DRK_V + v];
+    xs[i] = val;
+  }
+  __syncthreads();
+  const int co = threadIdx.x & 127, ph = threadIdx.x >> 7;
+  float acc[DRK_TAPS * DRK_V];
+#pragma unroll
+  for (int k = 0; k < DRK_TAPS * DRK_V; ++k) acc[k] = 0.f;
+  for (int rr = ph; rr < 64; rr += 2) {
+    const long row = r0 + rr;
+    if (row >= M) break;
+    const int p = (int)(row % L);
+    const float d = dpre[row * DRK_C + co];
+#pragma unroll
+    for (int t = 0; t < DRK_TAPS; ++t) {
+      const int pp = p + t - 4;
+      if (pp >= 0 && pp < L) {
+#pragma unroll
+        for (int v = 0; v < DRK_V; ++v) acc[t * DRK_V + v] += d * xs[(rr + t) * DRK_V + v];
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < DRK_TAPS * DRK_V; ++k) pw[ph][k][co] = acc[k];
+  __syncthreads();
+  if (ph == 0) {
+#pragma unroll
+    for (int k = 0; k < DRK_TAPS * DRK_V; ++k) atomicAdd(dw_t + k * DRK_C + co, pw[0][k][co] + pw[1][k][co]);
+  }
+}
+
+// one wave per (row, all 5 v): lane = co pair; 9 taps; shuffle-reduce over the wave
+__global__ void __launch_bounds__(256) k_stem_dgrad(const float* __restrict__ dpre, const float* __restrict__ w_t,
+                                                    float* __restrict__ dx, long M, int L) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int p = (int)(row % L);
+  float acc[DRK_V] = {0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < DRK_TAPS; ++t) {
+    const int pp = p - (t - 4);        // the output position this input fed through tap t
+    if (pp >= 0 && pp < L) {
+      const float* d = dpre + (row - (t - 4)) * DRK_C;
+      const float d0 = d[lane], d1 = d[lane + 64];
+#pragma unroll
+      for (int v = 0; v < DRK_V; ++v)
+        acc[v] += d0 * w_t[(t * DRK_V + v) * DRK_C + lane] + d1 * w_t[(t * DRK_V + v) * DRK_C + lane + 64];
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < DRK_V; ++v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) acc[v] += __shfl_xor(acc[v], o);
+  }
+  if (lane < DRK_V) {
+    float o = acc[0];
+#pragma unroll
+    for (int v = 1; v < DRK_V; ++v) o = (lane == v) ? acc[v] : o;
+    dx[row * DRK_V + lane] = o;
+  }
+}
+
+// ------------------------------------------------------------------------------------ time path backward
+// tbias[b][l][c] = dense_w[l][c][:] . temb[b][:] + dense_b[l][c];  temb = relu(lin_w . four + lin_b); four = sin/cos(sigma*W*2pi)
+// One workgroup (128 threads) per batch row; W (the Fourier frequencies) is not trained (dnaconv.py:17).
+__global__ void __launch_bounds__(128) k_time_bwd(const float* __restrict__ dtbias, const float* __restrict__ sigma,
+                                                  const float* __restrict__ W, const float* __restrict__ temb,
+                                                  const float* __restrict__ dense_w, float* __restrict__ d_dense_w,
+                                                  float* __restrict__ d_dense_b, float* __restrict__ d_lin_w,
+                                                  float* __restrict__ d_lin_b, int n_layers) {
+  __shared__ float te[DRK_C], dt[DRK_C], dpre[DRK_C], four[DRK_C];
+  const int b = blockIdx.x, c = threadIdx.x;
+  te[c] = temb[(long)b * DRK_C + c];
+  const float proj = ((sigma[b] * W[c & 63]) * 2.0f) * 3.14159274101257324f;
+  four[c] = (c < 64) ? sinf(proj) : cosf(proj);
+  float dtemb = 0.f;
+  for (int l = 0; l < n_layers; ++l) {
+    __syncthreads();
+    dt[c] = dtbias[((long)b * n_layers + l) * DRK_C + c];
+    __syncthreads();
+    atomicAdd(d_dense_b + l * DRK_C + c, dt[c]);
+    const float* wl = dense_w + (long)l * DRK_C * DRK_C;
+    float* dwl = d_dense_w + (long)l * DRK_C * DRK_C;
+    // thread c = INPUT index j here: dtemb[j] += sum_o dt[o] * w[o][j];  d_w[o][j] += dt[o] * te[j]
+    for (int o = 0; o < DRK_C; ++o) {
+      dtemb += dt[o] * wl[o * DRK_C + c];
+      atomicAdd(dwl + o * DRK_C + c, dt[o] * te[c]);
+    }
+  }
+  __syncthreads();
+  dpre[c] = te[c] > 0.f ? dtemb : 0.f;
+  __syncthreads();
+  atomicAdd(d_lin_b + c, dpre[c]);
+  for (int o = 0; o < DRK_C; ++o) atomicAdd(d_lin_w + o * DRK_C + c, dpre[o] * four[c]);
+}
+
+// ------------------------------------------------------------------------------------ SUBS backward
+// lp = SUBS(logits, tok): for masked rows dlogits_i = dlp_i - p_i * sum_{j<4} dlp_j (i<4, p = exp(lp)), dlogits_4 = 0
+// (its probability is exp(-1e6) = 0); rows holding a token are constants: dlogits = 0  (diffusion_gosai_update.py:250-252).
+__device__ __forceinline__ void subs_bwd_row(const float lp[DRK_V], const float dlp[DRK_V], int tok, float dl[DRK_V]) {
+  if (tok != DRK_MASK) {
+#pragma unroll
+    for (int v = 0; v < DRK_V; ++v) dl[v] = 0.f;
+    return;
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int v = 0; v < DRK_V; ++v) s += dlp[v];
+#pragma unroll
+  for (int v = 0; v < DRK_V; ++v) dl[v] = dlp[v] - expf(lp[v]) * s;
+}
+
+__device__ __forceinline__ int tok_of(const int64_t* x, const float* x_soft, long i) {
+  if (x) return (int)x[i];
+  int best = 0;
+#pragma unroll
+  for (int k = 1; k < DRK_V; ++k)
+    if (x_soft[i * DRK_V + k] > x_soft[i * DRK_V + best]) best = k;
+  return best;
+}
+
+__global__ void __launch_bounds__(256) k_subs_bwd(const float* __restrict__ logits, const int64_t* __restrict__ x,
+                                                  const float* __restrict__ x_soft, const float* __restrict__ dlogp,
+                                                  float* __restrict__ dlogits, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    float lg[DRK_V], lp[DRK_V], dlp[DRK_V], dl[DRK_V];
+#pragma unroll
+    for (int v = 0; v < DRK_V; ++v) {
+      lg[v] = logits[i * DRK_V + v];
+      dlp[v] = dlogp[i * DRK_V + v];
+    }
+    const int tok = tok_of(x, x_soft, i);
+    drk_subs_logp(lg, tok, lp);
+    subs_bwd_row(lp, dlp, tok, dl);
+#pragma unroll
+    for (int v = 0; v < DRK_V; ++v) dlogits[i * DRK_V + v] = dl[v];
+  }
+}
+
+// ------------------------------------------------------------------------------------ soft reverse step
+// _ddpm_update_finetune_gradient tail (diffusion_gosai_update.py:572-586) + _sample_categorical_gradient (:30-35):
+//   lp = SUBS(logits, argmax x);  q = exp(lp) * (mc_t - mc_s), q[mask] = mc_s;  g = 1e-10 - log(U + 1e-10)
+//   y = softmax((log q - log g) / temp);  flag = 1 - x[mask]  (or sigmoid((1 - x[mask]) / cft))
+//   x_next = flag * x + (1 - flag) * y
+__device__ __forceinline__ void soft_row(const float lg[DRK_V], const float xs[DRK_V], const float u[DRK_V], float mc_t,
+                                         float mc_s, float inv_temp, float cft, int& tok, float lp[DRK_V], float y[DRK_V],
+                                         float& flag) {
+  tok = 0;
+#pragma unroll
+  for (int k = 1; k < DRK_V; ++k)
+    if (xs[k] > xs[tok]) tok = k;
+  drk_subs_logp(lg, tok, lp);
+  float q[DRK_V], z[DRK_V];
+  drk_posterior(lp, mc_t, mc_s, q);
+  float m = -INFINITY;
+#pragma unroll
+  for (int v = 0; v < DRK_V; ++v) {
+    const float g = 1e-10f - logf(u[v] + 1e-10f);
+    z[v] = (logf(q[v]) - logf(g)) * inv_temp;
+    m = fmaxf(m, z[v]);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int v = 0; v < DRK_V; ++v) {
+    y[v] = expf(z[v] - m);
+    s += y[v];
+  }
+#pragma unroll
+  for (int v = 0; v < DRK_V; ++v) y[v] = y[v] / s;
+  const float cp = 1.0f - xs[DRK_MASK];
+  flag = (cft > 0.f) ? 1.0f / (1.0f + expf(-cp / cft)) : cp;
+}
+
+template <bool INJECT>
+__global__ void __launch_bounds__(256)
+    k_soft_step_fwd(const float* __restrict__ logits, const float* __restrict__ x_soft, const float* __restrict__ uniforms,
+                    float* __restrict__ x_next, float* __restrict__ flag_out, long n, int L, float mc_t, float mc_s,
+                    float inv_temp, float cft, uint64_t seed, uint32_t step, uint64_t sample_offset) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    float lg[DRK_V], xs[DRK_V], u[DRK_V], lp[DRK_V], y[DRK_V], flag;
+    int tok;
+#pragma unroll
+    for (int v = 0; v < DRK_V; ++v) {
+      lg[v] = logits[i * DRK_V + v];
+      xs[v] = x_soft[i * DRK_V + v];
+    }
+    if (INJECT) {
+#pragma unroll
+      for (int v = 0; v < DRK_V; ++v) u[v] = uniforms[i * DRK_V + v];
+    } else {
+      drk_step_uniforms(seed, step, sample_offset + (uint64_t)(i / L), (uint32_t)(i % L), u);
+    }
+    soft_row(lg, xs, u, mc_t, mc_s, inv_temp, cft, tok, lp, y, flag);
+#pragma unroll
+    for (int v = 0; v < DRK_V; ++v) x_next[i * DRK_V + v] = flag * xs[v] + (1.0f - flag) * y[v];
+    flag_out[i] = flag;
+  }
+}
+
+// Backward: given G = dL/dx_next (and optionally Gf = dL/dflag from a use of the returned flag):
+//   dL/dx (direct part) and dL/dlogits; the forward row is recomputed from the same inputs.
+template <bool INJECT>
+__global__ void __launch_bounds__(256)
+    k_soft_step_bwd(const float* __restrict__ logits, const float* __restrict__ x_soft, const float* __restrict__ uniforms,
+                    const float* __restrict__ gnext, const float* __restrict__ gflag, float* __restrict__ dlogits,
+                    float* __restrict__ dx, long n, int L, float mc_t, float mc_s, float inv_temp, float cft, uint64_t seed,
+                    uint32_t step, uint64_t sample_offset) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    float lg[DRK_V], xs[DRK_V], u[DRK_V], lp[DRK_V], y[DRK_V], G[DRK_V], flag;
+    int tok;
+#pragma unroll
+    for (int v = 0; v < DRK_V; ++v) {
+      lg[v] = logits[i * DRK_V + v];
+      xs[v] = x_soft[i * DRK_V + v];
+      G[v] = gnext[i * DRK_V + v];
+    }
+    if (INJECT) {
+#pragma unroll
+      for (int v = 0; v < DRK_V; ++v) u[v] = uniforms[i * DRK_V + v];
+    } else {
+      drk_step_uniforms(seed, step, sample_offset + (uint64_t)(i / L), (uint32_t)(i % L), u);
+    }
+    soft_row(lg, xs, u, mc_t, mc_s, inv_temp, cft, tok, lp, y, flag);
+    float dflag = gflag ? gflag[i] : 0.f;
+    float dyy = 0.f, dy[DRK_V], dxo[DRK_V];
+#pragma unroll
+    for (int v = 0; v < DRK_V; ++v) {
+      dflag += G[v] * (xs[v] - y[v]);
+      dy[v] = (1.0f - flag) * G[v];
+      dyy += y[v] * dy[v];
+      dxo[v] = flag * G[v];
+    }
+    dxo[DRK_MASK] += (cft > 0.f) ? -dflag * flag * (1.0f - flag) / cft : -dflag;
+    float dlp[DRK_V], dl[DRK_V];
+#pragma unroll
+    for (int v = 0; v < DRK_V; ++v) dlp[v] = y[v] * (dy[v] - dyy) * inv_temp;   // d/d log q = d/d lp for v < 4
+    dlp[DRK_MASK] = 0.f;                                                        // q[mask] = mc_s is a constant
+    subs_bwd_row(lp, dlp, tok, dl);
+#pragma unroll
+    for (int v = 0; v < DRK_V; ++v) {
+      dlogits[i * DRK_V + v] = dl[v];
+      dx[i * DRK_V + v] = dxo[v];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ C ABI
+extern "C" int drk_mask_mul(const float* g, const unsigned char* mask, float* out, long n, void* stream) {
+  ARGCHECK(n >= 0 && (n % 4) == 0, "drk_mask_mul");
+  if (n == 0) return DRK_OK;
+  ARGCHECK(g && mask && out, "drk_mask_mul");
+  hipLaunchKernelGGL(k_mask_mul, dim3(grid_for(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, g, mask, out, n / 4);
+  DRK_CHECK_LAUNCH();
+  return DRK_OK;
+}
+
+extern "C" int drk_relu_bwd(const float* g, const float* y, float* out, long n, void* stream) {
+  ARGCHECK(n >= 0 && (n % 4) == 0, "drk_relu_bwd");
+  if (n == 0) return DRK_OK;
+  ARGCHECK(g && y && out, "drk_relu_bwd");
+  hipLaunchKernelGGL(k_relu_bwd, dim3(grid_for(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, g, y, out, n / 4);
+  DRK_CHECK_LAUNCH();
+  return DRK_OK;
+}
+
+extern "C" int drk_colsum128(const float* x, float* out, long n_seg, long seg_rows, void* stream) {
+  ARGCHECK(n_seg >= 0 && seg_rows >= 0 && n_seg < 65536, "drk_colsum128");
+  if (n_seg == 0 || seg_rows == 0) return DRK_OK;
+  ARGCHECK(x && out, "drk_colsum128");
+  hipLaunchKernelGGL(k_colsum128, dim3((unsigned)((seg_rows + 63) / 64), (unsigned)n_seg), dim3(256), 0,
+                     (hipStream_t)stream, x, out, seg_rows);
+  DRK_CHECK_LAUNCH();
+  return DRK_OK;
+}
+
+extern "C" int drk_ln_bwd(const float* dh, const float* feat, const float* tbias, long tbias_bstride, const float* gamma,
+                          const float* mean, const float* rstd, const float* g_resid, float* dxin, float* dfeat,
+                          float* dgamma, float* dbeta, int B, int L, void* stream) {
+  DRK_SHAPE_GUARD("drk_ln_bwd");
+  ARGCHECK(dh && feat && gamma && mean && rstd && dxin && dfeat && dgamma && dbeta, "drk_ln_bwd");
+  const long M = (long)B * L;
+  hipLaunchKernelGGL(k_ln_bwd, dim3((unsigned)((M + 63) / 64)), dim3(256), 0, (hipStream_t)stream, dh, feat, tbias,
+                     tbias_bstride, gamma, mean, rstd, g_resid, dxin, dfeat, dgamma, dbeta, M, L);
+  DRK_CHECK_LAUNCH();
+  return DRK_OK;
+}
+
+extern "C" int drk_conv_wgrad_f32(const float* h, const float* dc, float* dwt, int B, int L, int taps, int dilation,
+                                  void* stream) {
+  DRK_SHAPE_GUARD("drk_conv_wgrad_f32");
+  ARGCHECK(h && dc && dwt && taps >= 1 && (taps & 1) && dilation >= 0, "drk_conv_wgrad_f32");
+  const long M = (long)B * L;
+  hipLaunchKernelGGL(k_conv_wgrad, dim3((unsigned)((M + WG_ROWS - 1) / WG_ROWS), (unsigned)taps), dim3(256), 0,
+                     (hipStream_t)stream, h, dc, dwt, M, L, taps, dilation);
+  DRK_CHECK_LAUNCH();
+  return DRK_OK;
+}
+
+extern "C" int drk_head_out_bwd(const float* dlogits, const float* y, const float* w, float* dy, float* dw, float* db,
+                                int B, int L, void* stream) {
+  DRK_SHAPE_GUARD("drk_head_out_bwd");
+  ARGCHECK(dlogits && y && w && dy && dw && db, "drk_head_out_bwd");
+  const long M = (long)B * L;
+  hipLaunchKernelGGL(k_head_out_bwd, dim3((unsigned)((M + 63) / 64)), dim3(256), 0, (hipStream_t)stream, dlogits, y, w,
+                     dy, dw, db, M);
+  DRK_CHECK_LAUNCH();
+  return DRK_OK;
+}
+
+extern "C" int drk_stem_bwd(const float* dpre, const int64_t* x, const float* x_soft, const float* w_t, float* dw_t,
+                            float* dx, int B, int L, void* stream) {
+  DRK_SHAPE_GUARD("drk_stem_bwd");
+  ARGCHECK(dpre && (x || x_soft) && w_t && dw_t, "drk_stem_bwd");
+  const long M = (long)B * L;
+  hipLaunchKernelGGL(k_stem_wgrad, dim3((unsigned)((M + 63) / 64)), dim3(256), 0, (hipStream_t)stream, dpre, x, x_soft,
+                     dw_t, M, L);
+  DRK_CHECK_LAUNCH();
+  if (dx) {
+    hipLaunchKernelGGL(k_stem_dgrad, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, dpre, w_t, dx, M, L);
+    DRK_CHECK_LAUNCH();
+  }
+  return DRK_OK;
+}
+
+extern "C" int drk_time_bwd(const float* dtbias, const float* sigma, int nb, const float* W, const float* temb,
+                            const float* dense_w, int n_layers, float* d_dense_w, float* d_dense_b, float* d_lin_w,
+                            float* d_lin_b, void* stream) {
+  ARGCHECK(nb >= 0 && n_layers > 0, "drk_time_bwd");
+  if (nb == 0) return DRK_OK;
+  ARGCHECK(dtbias && sigma && W && temb && dense_w && d_dense_w && d_dense_b && d_lin_w && d_lin_b, "drk_time_bwd");
+  hipLaunchKernelGGL(k_time_bwd, dim3(nb), dim3(128), 0, (hipStream_t)stream, dtbias, sigma, W, temb, dense_w, d_dense_w,
+                     d_dense_b, d_lin_w, d_lin_b, n_layers);
+  DRK_CHECK_LAUNCH();
+  return DRK_OK;
+}
+
+extern "C" int drk_subs_bwd(const float* logits, const int64_t* x, const float* x_soft, const float* dlogp,
+                            float* dlogits, int B, int L, void* stream) {
+  DRK_SHAPE_GUARD("drk_subs_bwd");
+  ARGCHECK(logits && (x || x_soft) && dlogp && dlogits, "drk_subs_bwd");
+  const long n = (long)B * L;
+  hipLaunchKernelGGL(k_subs_bwd, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, logits, x, x_soft, dlogp,
+                     dlogits, n);
+  DRK_CHECK_LAUNCH();
+  return DRK_OK;
+}
+
+extern "C" int drk_reverse_step_soft_fwd(const float* logits, const float* x_soft, const float* uniforms, float* x_next,
+                                         float* flag, int B, int L, float mc_t, float mc_s, float temp,
+                                         float copy_flag_temp, uint64_t seed, uint32_t step, uint64_t sample_offset,
+                                         void* stream) {
+  DRK_SHAPE_GUARD("drk_reverse_step_soft_fwd");
+  ARGCHECK(logits && x_soft && x_next && flag && temp > 0.f, "drk_reverse_step_soft_fwd");
+  const long n = (long)B * L;
+  if (uniforms)
+    hipLaunchKernelGGL(k_soft_step_fwd<true>, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, logits, x_soft,
+                       uniforms, x_next, flag, n, L, mc_t, mc_s, 1.0f / temp, copy_flag_temp, seed, step, sample_offset);
+  else
+    hipLaunchKernelGGL(k_soft_step_fwd<false>, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, logits, x_soft,
+                       uniforms, x_next, flag, n, L, mc_t, mc_s, 1.0f / temp, copy_flag_temp, seed, step, sample_offset);
+  DRK_CHECK_LAUNCH();
+  return DRK_OK;
+}
+
+extern "C" int drk_reverse_step_soft_bwd(const float* logits, const float* x_soft, const float* uniforms,
+                                         const float* grad_x_next, const float* grad_flag, float* dlogits, float* dx, int B,
+                                         int L, float mc_t, float mc_s, float temp, float copy_flag_temp, uint64_t seed,
+                                         uint32_t step, uint64_t sample_offset, void* stream) {
+  DRK_SHAPE_GUARD("drk_reverse_step_soft_bwd");
+  ARGCHECK(logits && x_soft && grad_x_next && dlogits && dx && temp > 0.f, "drk_reverse_step_soft_bwd");
+  const long n = (long)B * L;
+  if (uniforms)
+    hipLaunchKernelGGL(k_soft_step_bwd<true>, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, logits, x_soft,
+                       uniforms, grad_x_next, grad_flag, dlogits, dx, n, L, mc_t, mc_s, 1.0f / temp, copy_flag_temp, seed,
+                       step, sample_offset);
+  else
+    hipLaunchKernelGGL(k_soft_step_bwd<false>, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, logits, x_soft,
+                       uniforms, grad_x_next, grad_flag, dlogits, dx, n, L, mc_t, mc_s, 1.0f / temp, copy_flag_temp, seed,
+                       step, sample_offset);
+  DRK_CHECK_LAUNCH();
+  return DRK_OK;
+}

@@ -71,6 +71,9 @@ class Diffusion(nn.Module):
     def _subs_parameterization(self, logits, xt):
         """reference :243-253 (one fused kernel; writes into `logits` like the reference)."""
         xt = xt if xt.dtype == torch.int64 else xt.contiguous()
+        if torch.is_grad_enabled() and logits.requires_grad:
+            from .autograd import subs_with_grad
+            return subs_with_grad(logits, xt)
         return ops.subs_fwd(logits, xt, out=logits)
 
     def forward(self, x, sigma):

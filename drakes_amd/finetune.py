@@ -1,0 +1,90 @@
+"""Diffusion._sample_finetune_gradient / _ddpm_update_finetune_gradient on the HIP kernels
+(reference: /root/reference/drakes_dna/diffusion_gosai_update.py:552-630).
+
+The first num_steps - truncate_steps steps are hard steps without a graph (the reference builds
+one and drops it, :616-619); the last truncate_steps steps are Gumbel-softmax steps whose chain
+is differentiable w.r.t. the denoiser parameters (drakes_amd/autograd.py).
+"""
+import torch
+import torch.nn.functional as F
+
+from . import autograd, noise_schedule, ops
+
+
+def _scalars(model, t, dt):
+    """sigma_t [B], move_chance_t/s as the reference computes them (:557-568)."""
+    sigma_t, _ = model.noise(t)
+    sigma_s, _ = model.noise(t - dt)
+    if sigma_t.ndim > 1:
+        sigma_t = sigma_t.squeeze(-1)
+    if sigma_s.ndim > 1:
+        sigma_s = sigma_s.squeeze(-1)
+    return sigma_t, 1 - torch.exp(-sigma_t), 1 - torch.exp(-sigma_s)
+
+
+def ddpm_update_finetune_gradient(model, x, t, dt, copy_flag_temp, return_process=False, *, seed=None, step=0,
+                                  sample_offset=0, uniforms=None):
+    """One soft reverse step (:552-586).  x: int64 [B,L] or float32 [B,L,5]; t [B,1], all rows equal."""
+    if x.ndim == 2 or x.shape[-1] != model.vocab_size:
+        x = F.one_hot(x, num_classes=model.vocab_size).to(torch.float32)
+    sigma_t, mct, mcs = _scalars(model, t, dt)
+    if not (bool((mct == mct[0]).all()) and bool((mcs == mcs[0]).all())):
+        raise NotImplementedError('per-row timesteps: the fused step takes one (mc_t, mc_s) per call')
+    if seed is None and uniforms is None:
+        seed = model._draw_seed()
+    sig = model._process_sigma(sigma_t)[:1]            # one shared value (all rows are equal)
+    logits = autograd.backbone_with_grad(model.backbone, x, sig)
+    x_next, flag = autograd.soft_step_with_grad(logits, x, float(mct[0]), float(mcs[0]),
+                                                float(model.config.finetuning.gumbel_softmax_temp), copy_flag_temp,
+                                                seed or 0, step, sample_offset, uniforms)
+    if return_process:
+        return x_next, x, sigma_t, mct[:, None, None], flag
+    return x_next
+
+
+def sample_finetune_gradient(model, num_steps=None, eps=1e-5, eval_sp_size=None, copy_flag_temp=None, *, seed=None,
+                             sample_offset=0, uniforms=None):
+    assert model.parameterization == 'subs' and model.sampler == 'ddpm'
+    batch = model.config.loader.eval_batch_size if eval_sp_size is None else eval_sp_size
+    if num_steps is None:
+        num_steps = model.config.sampling.steps
+    L = model.config.model.length
+    dev = model.device
+    if seed is None:
+        seed = model._draw_seed()
+    trunc = model.config.finetuning.truncate_steps
+    temp = float(model.config.finetuning.gumbel_softmax_temp)
+    table, _, _, _ = noise_schedule.step_table(model.noise, num_steps, eps)
+    table = table.tolist()
+    bb = model.backbone
+    x = model._sample_prior(batch, L).to(dev)
+    last_x_list, condt_list, move_chance_t_list, copy_flag_list = [], [], [], []
+    shared = None
+    for i in range(num_steps):
+        _, sigma_t, mc_t, mc_s = table[i]
+        u = uniforms(i) if uniforms is not None else None
+        condt = torch.full((batch,), sigma_t, dtype=torch.float32, device=dev)
+        mct = torch.full((batch, 1, 1), mc_t, dtype=torch.float32, device=dev)
+        if i < num_steps - trunc:                                           # hard step, no graph (:615-619)
+            with torch.no_grad():
+                if model.time_conditioning or shared is None:
+                    shared = model._shared_time_bias(sigma_t)
+                logits = bb.forward_f32(x, shared, 0, model._work)
+                x_next = ops.reverse_step_hard(logits, x, mc_t, mc_s, seed, i, sample_offset, u)
+                last_x = F.one_hot(x, num_classes=model.vocab_size).to(torch.float32)
+                copy_flag = (x != model.mask_index).to(x.dtype).unsqueeze(-1)
+            x = x_next
+        else:                                                               # soft step (:621, :552-586)
+            if x.ndim == 2:
+                x = F.one_hot(x, num_classes=model.vocab_size).to(torch.float32)
+            sig = torch.full((1,), sigma_t if model.time_conditioning else 0.0, dtype=torch.float32, device=dev)
+            logits = autograd.backbone_with_grad(bb, x, sig)
+            last_x = x
+            x, copy_flag = autograd.soft_step_with_grad(logits, x, mc_t, mc_s, temp, copy_flag_temp, seed, i,
+                                                        sample_offset, u)
+        last_x_list.append(last_x)
+        condt_list.append(condt)
+        move_chance_t_list.append(mct)
+        copy_flag_list.append(copy_flag)
+    x_argmax = F.one_hot(x[:, :, :-1].argmax(dim=-1), num_classes=model.vocab_size - 1).to(torch.float32)
+    return x[:, :, :-1] + (x_argmax - x[:, :, :-1]).detach(), last_x_list, condt_list, move_chance_t_list, copy_flag_list

@@ -88,6 +88,9 @@ class CNNModel(nn.Module):
                     'ln_g': [self.norms[i].weight.detach().contiguous() for i in range(n)],
                     'ln_b': [self.norms[i].bias.detach().contiguous() for i in range(n)],
                     'conv_w': [ops.pack_conv_weight_f32(self.convs[i].weight) for i in range(n)],
+                    # input-gradient weights: the same kernel run on weight.transpose(0,1).flip(2)
+                    'conv_wT': [ops.pack_conv_weight_f32(self.convs[i].weight.transpose(0, 1).flip(2)) for i in range(n)],
+                    'head0_wT': ops.pack_conv_weight_f32(self.final_conv[0].weight.transpose(0, 1)),
                     'conv_b': [self.convs[i].bias.detach().contiguous() for i in range(n)],
                     'head0_w': ops.pack_conv_weight_f32(self.final_conv[0].weight),
                     'head0_b': self.final_conv[0].bias.detach().contiguous(),
@@ -133,6 +136,6 @@ class CNNModel(nn.Module):
             seq = seq.long()
         if torch.is_grad_enabled() and (seq.requires_grad or any(p.requires_grad for p in self.parameters())):
             from ..autograd import backbone_with_grad
-            return backbone_with_grad(self, seq, t)
+            return backbone_with_grad(self, seq.contiguous(), t.to(torch.float32))
         tbias = self.time_bias(t.to(torch.float32))
         return self.forward_f32(seq.contiguous(), tbias, tbias.stride(0))

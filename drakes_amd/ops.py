@@ -154,12 +154,12 @@ def ln_fwd(feat, tbias_layer, tb_stride, gamma, beta, out=None, mean=None, rstd=
     return out
 
 
-def conv_fwd_f32(h, w_pk, bias, resid, dilation, relu=True, out=None):
+def conv_fwd_f32(h, w_pk, bias, resid, dilation, relu=True, out=None, relu_mask=None):
     B, L, _ = h.shape
     taps = w_pk.shape[0]
     out = out if out is not None else torch.empty_like(h)
-    args = (_f(h, 'h'), _f(w_pk, 'w_pk'), _f(bias, 'bias'), _f(resid, 'resid'), _f(out, 'out'), B, L, taps, dilation,
-            1 if relu else 0, _stream())
+    args = (_f(h, 'h'), _f(w_pk, 'w_pk'), _f(bias, 'bias'), _f(resid, 'resid'), _f(out, 'out'),
+            _dev_ptr(relu_mask, torch.uint8, 'relu_mask'), B, L, taps, dilation, 1 if relu else 0, _stream())
     if taps == 9:
         PROFILE.bracket('k_conv_f32<2>', 2.0 * B * L * C * C * taps, lambda: _lib.call('drk_conv_fwd_f32', *args))
     else:
@@ -172,6 +172,97 @@ def head_out_fwd(y, w, bias, out=None):
     out = out if out is not None else torch.empty(B, L, V, dtype=torch.float32, device=y.device)
     _lib.call('drk_head_out_fwd', _f(y, 'y'), _f(w, 'w'), _f(bias, 'bias'), _f(out, 'logits'), B, L, _stream())
     return out
+
+
+# ---- backward ops ---------------------------------------------------------------------------------
+def mask_mul(g, mask, out=None):
+    out = out if out is not None else torch.empty_like(g)
+    _lib.call('drk_mask_mul', _f(g, 'g'), _dev_ptr(mask, torch.uint8, 'mask'), _f(out, 'out'), g.numel(), _stream())
+    return out
+
+
+def relu_bwd(g, y, out=None):
+    out = out if out is not None else torch.empty_like(g)
+    _lib.call('drk_relu_bwd', _f(g, 'g'), _f(y, 'y'), _f(out, 'out'), g.numel(), _stream())
+    return out
+
+
+def colsum128(x, n_seg, seg_rows, out):
+    """out [n_seg, 128] += column sums of x viewed as [n_seg * seg_rows, 128]."""
+    _lib.call('drk_colsum128', _f(x, 'x'), _f(out, 'out'), n_seg, seg_rows, _stream())
+    return out
+
+
+def ln_bwd(dh, feat, tbias_layer, tb_stride, gamma, mean, rstd, g_resid, dxin, dfeat, dgamma, dbeta):
+    B, L, _ = feat.shape
+    tb = ctypes.c_void_p(tbias_layer.data_ptr()) if tbias_layer is not None else None
+    _lib.call('drk_ln_bwd', _f(dh, 'dh'), _f(feat, 'feat'), tb, tb_stride, _f(gamma, 'gamma'), _f(mean, 'mean'),
+              _f(rstd, 'rstd'), _f(g_resid, 'g_resid'), _f(dxin, 'dxin'), _f(dfeat, 'dfeat'), _f(dgamma, 'dgamma'),
+              _f(dbeta, 'dbeta'), B, L, _stream())
+
+
+def conv_wgrad_f32(h, dc, dwt, dilation):
+    """dwt [taps,128(ci),128(co)] += ..."""
+    B, L, _ = h.shape
+    _lib.call('drk_conv_wgrad_f32', _f(h, 'h'), _f(dc, 'dc'), _f(dwt, 'dwt'), B, L, dwt.shape[0], dilation, _stream())
+
+
+def head_out_bwd(dlogits, y, w, dy, dw, db):
+    B, L, _ = y.shape
+    _lib.call('drk_head_out_bwd', _f(dlogits, 'dlogits'), _f(y, 'y'), _f(w, 'w'), _f(dy, 'dy'), _f(dw, 'dw'),
+              _f(db, 'db'), B, L, _stream())
+
+
+def stem_bwd(dpre, x, w_t, dw_t, dx):
+    B, L = x.shape[0], x.shape[1]
+    if x.dtype == torch.int64:
+        _lib.call('drk_stem_bwd', _f(dpre, 'dpre'), _i(x, 'x'), None, _f(w_t, 'w_t'), _f(dw_t, 'dw_t'), None, B, L,
+                  _stream())
+    else:
+        _lib.call('drk_stem_bwd', _f(dpre, 'dpre'), None, _f(x, 'x_soft'), _f(w_t, 'w_t'), _f(dw_t, 'dw_t'),
+                  _f(dx, 'dx'), B, L, _stream())
+
+
+def time_bwd(dtbias, sigma, W, temb, dense_w, d_dense_w, d_dense_b, d_lin_w, d_lin_b):
+    nb, n_layers = dtbias.shape[0], dtbias.shape[1]
+    _lib.call('drk_time_bwd', _f(dtbias, 'dtbias'), _f(sigma, 'sigma'), nb, _f(W, 'W'), _f(temb, 'temb'),
+              _f(dense_w, 'dense_w'), n_layers, _f(d_dense_w, 'd_dense_w'), _f(d_dense_b, 'd_dense_b'),
+              _f(d_lin_w, 'd_lin_w'), _f(d_lin_b, 'd_lin_b'), _stream())
+
+
+def subs_bwd(logits, x, dlogp, out=None):
+    B, L, _ = logits.shape
+    out = out if out is not None else torch.empty_like(logits)
+    if x.dtype == torch.int64:
+        _lib.call('drk_subs_bwd', _f(logits, 'logits'), _i(x, 'x'), None, _f(dlogp, 'dlogp'), _f(out, 'dlogits'), B, L,
+                  _stream())
+    else:
+        _lib.call('drk_subs_bwd', _f(logits, 'logits'), None, _f(x, 'x_soft'), _f(dlogp, 'dlogp'), _f(out, 'dlogits'),
+                  B, L, _stream())
+    return out
+
+
+def reverse_step_soft_fwd(logits, x_soft, mc_t, mc_s, temp, copy_flag_temp, seed=0, step=0, sample_offset=0,
+                          uniforms=None):
+    B, L, _ = x_soft.shape
+    x_next = torch.empty_like(x_soft)
+    flag = torch.empty(B, L, dtype=torch.float32, device=x_soft.device)
+    _lib.call('drk_reverse_step_soft_fwd', _f(logits, 'logits'), _f(x_soft, 'x_soft'), _f(uniforms, 'uniforms'),
+              _f(x_next, 'x_next'), _f(flag, 'flag'), B, L, float(mc_t), float(mc_s), float(temp),
+              float(copy_flag_temp) if copy_flag_temp is not None else 0.0, seed, step, sample_offset, _stream())
+    return x_next, flag
+
+
+def reverse_step_soft_bwd(logits, x_soft, grad_x_next, grad_flag, mc_t, mc_s, temp, copy_flag_temp, seed=0, step=0,
+                          sample_offset=0, uniforms=None):
+    B, L, _ = x_soft.shape
+    dlogits = torch.empty_like(logits)
+    dx = torch.empty_like(x_soft)
+    _lib.call('drk_reverse_step_soft_bwd', _f(logits, 'logits'), _f(x_soft, 'x_soft'), _f(uniforms, 'uniforms'),
+              _f(grad_x_next, 'grad_x_next'), _f(grad_flag, 'grad_flag'), _f(dlogits, 'dlogits'), _f(dx, 'dx'), B, L,
+              float(mc_t), float(mc_s), float(temp), float(copy_flag_temp) if copy_flag_temp is not None else 0.0, seed,
+              step, sample_offset, _stream())
+    return dlogits, dx
 
 
 # ---- weight layouts the kernels read (pure index permutations) --------------------------------

@@ -83,12 +83,62 @@ int drk_ln_fwd(const float* feat, const float* tbias, long tbias_bstride, const 
                const float* beta, float* h, float* mean, float* rstd, int B, int L, void* stream);
 /* feat_out = relu(Conv1d(128->128,k=taps,dilation)(h) + bias) [+ resid] — dnaconv.py:96-98 and,
  * with taps=1 and resid=NULL, final_conv.0 + ReLU (:61-62,101).  Exact fp32 (f32-input MFMA).
- * w_pk [taps][32][128][4]: w_pk[t][g][co][q] = weight[co][4g+q][t]. */
+ * w_pk [taps][32][128][4]: w_pk[t][g][co][q] = weight[co][4g+q][t].  bias may be NULL (= 0).
+ * relu_mask: optional uint8 [B][L][128] = (pre-activation > 0), kept for the backward pass.
+ * The same kernel is the convolution's input gradient: feed dc, the weights packed from
+ * weight.transpose(0,1).flip(2), bias = NULL, relu = 0. */
 int drk_conv_fwd_f32(const float* h, const float* w_pk, const float* bias, const float* resid, float* out,
-                     int B, int L, int taps, int dilation, int relu, void* stream);
+                     unsigned char* relu_mask, int B, int L, int taps, int dilation, int relu, void* stream);
 /* logits = Conv1d(128->5,k=1)(y) — dnaconv.py:63,101-102.  w [5][128]; logits [B][L][5]. */
 int drk_head_out_fwd(const float* y, const float* w, const float* bias, float* logits, int B, int L,
                      void* stream);
+
+/* ---- backward ops (fp32) -----------------------------------------------------------------------
+ * The reference gets these from torch autograd over CNNModel.forward (models/dnaconv.py:74-110),
+ * _subs_parameterization (:243-253) and _ddpm_update_finetune_gradient (:552-586).  Parameter
+ * gradients are ACCUMULATED (fp32 atomics) into buffers the caller zeroes. */
+/* out = g * mask (ReLU backward from the mask of drk_conv_fwd_f32); n % 4 == 0. */
+int drk_mask_mul(const float* g, const unsigned char* mask, float* out, long n, void* stream);
+/* out = g * (y > 0) (ReLU backward from a saved ReLU output); n % 4 == 0. */
+int drk_relu_bwd(const float* g, const float* y, float* out, long n, void* stream);
+/* out[seg][128] += column sums of x[seg*seg_rows .. +seg_rows][128] (bias / time-bias gradients). */
+int drk_colsum128(const float* x, float* out, long n_seg, long seg_rows, void* stream);
+/* LayerNorm backward of drk_ln_fwd: dxin, dfeat = dxin + g_resid (g_resid may be NULL), dgamma/dbeta accumulated. */
+int drk_ln_bwd(const float* dh, const float* feat, const float* tbias, long tbias_bstride, const float* gamma,
+               const float* mean, const float* rstd, const float* g_resid, float* dxin, float* dfeat,
+               float* dgamma, float* dbeta, int B, int L, void* stream);
+/* Conv1d weight gradient: dwt[t][ci][co] += sum_rows h[row + (t - taps/2)*dilation][ci] * dc[row][co]. */
+int drk_conv_wgrad_f32(const float* h, const float* dc, float* dwt, int B, int L, int taps, int dilation,
+                       void* stream);
+/* Backward of drk_head_out_fwd: dy [B][L][128]; dw [5][128], db [5] accumulated. */
+int drk_head_out_bwd(const float* dlogits, const float* y, const float* w, float* dy, float* dw, float* db,
+                     int B, int L, void* stream);
+/* Backward of drk_stem_fwd from dpre = dfeat * (feat > 0): dw_t [9][5][128] accumulated; dx [B][L][5]
+ * (NULL for token input: no gradient flows into integer tokens). */
+int drk_stem_bwd(const float* dpre, const int64_t* x, const float* x_soft, const float* w_t, float* dw_t,
+                 float* dx, int B, int L, void* stream);
+/* Backward of drk_time_bias_fwd + drk_time_embed_fwd from dtbias [nb][n_layers][128]; all outputs accumulated. */
+int drk_time_bwd(const float* dtbias, const float* sigma, int nb, const float* W, const float* temb,
+                 const float* dense_w, int n_layers, float* d_dense_w, float* d_dense_b, float* d_lin_w,
+                 float* d_lin_b, void* stream);
+/* Backward of drk_subs_fwd: rows holding a token are constants (dlogits = 0), :250-252. */
+int drk_subs_bwd(const float* logits, const int64_t* x, const float* x_soft, const float* dlogp, float* dlogits,
+                 int B, int L, void* stream);
+
+/* ---- reverse step (soft, Gumbel-softmax) --------------------------------------------------------
+ * _subs_parameterization + the tail of _ddpm_update_finetune_gradient (:572-586) +
+ * _sample_categorical_gradient (:30-35).  x_soft, x_next float32 [B][L][5]; flag [B][L] is the soft copy
+ * flag (:577-581); copy_flag_temp <= 0 means None.  The backward recomputes the forward row from the
+ * same inputs and returns dL/dlogits and the DIRECT part of dL/dx_soft (the part through the
+ * denoiser input comes from drk_stem_bwd). */
+int drk_reverse_step_soft_fwd(const float* logits, const float* x_soft, const float* uniforms, float* x_next,
+                              float* flag, int B, int L, float mc_t, float mc_s, float temp,
+                              float copy_flag_temp, uint64_t seed, uint32_t step, uint64_t sample_offset,
+                              void* stream);
+int drk_reverse_step_soft_bwd(const float* logits, const float* x_soft, const float* uniforms,
+                              const float* grad_x_next, const float* grad_flag, float* dlogits, float* dx, int B,
+                              int L, float mc_t, float mc_s, float temp, float copy_flag_temp, uint64_t seed,
+                              uint32_t step, uint64_t sample_offset, void* stream);
 
 /* ---- fused sampling loop, bf16 MFMA ----------------------------------------------------------- */
 /* The whole of Diffusion._sample (diffusion_gosai_update.py:506-550, ddpm predictor) in one launch:

@@ -75,7 +75,7 @@ def time_embedding(sd, sigma):
                            sd['backbone.time_embedder.1.bias']))
 
 
-def cnn_forward(sd, seq, sigma, return_feats=False):
+def cnn_forward(sd, seq, sigma, return_feats=False, preacts=None):
     """CNNModel.forward — models/dnaconv.py:74-110 (clean_data=False, no cfg, p_drop=0).
 
     seq: int64 [B,L] or float [B,L,5]; sigma: [B].  Returns logits [B,L,5]."""
@@ -94,12 +94,17 @@ def cnn_forward(sd, seq, sigma, return_feats=False):
         C = h.shape[1]
         h = F.layer_norm(h.permute(0, 2, 1), (C,), sd[f'backbone.norms.{i}.weight'],
                          sd[f'backbone.norms.{i}.bias'])
-        h = F.relu(F.conv1d(h.permute(0, 2, 1), sd[f'backbone.convs.{i}.weight'],
-                            sd[f'backbone.convs.{i}.bias'], dilation=d, padding=4 * d))
+        c = F.conv1d(h.permute(0, 2, 1), sd[f'backbone.convs.{i}.weight'],
+                     sd[f'backbone.convs.{i}.bias'], dilation=d, padding=4 * d)
+        if preacts is not None:      # tests: how close any ReLU argument sits to its kink
+            preacts.append(c.detach())
+        h = F.relu(c)
         feat = h + feat
         feats.append(feat)
-    y = F.relu(F.conv1d(feat, sd['backbone.final_conv.0.weight'], sd['backbone.final_conv.0.bias']))
-    y = F.conv1d(y, sd['backbone.final_conv.2.weight'], sd['backbone.final_conv.2.bias'])
+    c = F.conv1d(feat, sd['backbone.final_conv.0.weight'], sd['backbone.final_conv.0.bias'])
+    if preacts is not None:
+        preacts.append(c.detach())
+    y = F.conv1d(F.relu(c), sd['backbone.final_conv.2.weight'], sd['backbone.final_conv.2.bias'])
     logits = y.permute(0, 2, 1)
     if return_feats:
         return logits, feats

@@ -1,0 +1,170 @@
+"""Gumbel-softmax reverse step, denoiser backward and _sample_finetune_gradient against the
+oracle (torch autograd on the pinned CPU restatement) and the reference's golden vectors.
+
+Floating-point bars (fp32): forward values 2e-4 abs / 1e-4 rel; gradients 2e-3 of the tensor's
+largest |gradient| (parameter gradients are sums over up to B*L*steps terms accumulated with fp32
+atomics in a different order than torch's), global gradient norm 1e-3 relative."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import drakes_amd
+from conftest import load_golden
+from drakes_amd import autograd, ops
+from oracle import drakes_oracle as O
+from oracle import philox
+
+pytestmark = pytest.mark.gpu
+GTOL = 2e-3
+
+
+def relerr(got, ref):
+    return (got - ref).abs().max().item() / max(ref.abs().max().item(), 1e-12)
+
+
+@pytest.mark.parametrize('cft', [None, 0.5])
+def test_soft_step_forward_backward(dev, cft):
+    gen = np.random.Generator(np.random.PCG64(21))
+    B, L, temp = 5, 200, 0.8
+    logits = torch.from_numpy((gen.standard_normal((B, L, 5)) * 2).astype(np.float32))
+    x = torch.from_numpy(gen.dirichlet(np.ones(5) * 0.4, (B, L)).astype(np.float32))
+    x[0] = F.one_hot(torch.full((L,), 4), 5).float()               # fully masked rows (first soft step)
+    x[1] = F.one_hot(torch.from_numpy(gen.integers(0, 4, L)), 5).float()   # fully unmasked one-hot rows
+    u = torch.from_numpy(philox.step_uniforms(3, 9, B, L))
+    tab = O.step_scalars(128)
+    mc_t, mc_s = tab[100, 2], tab[100, 3]
+    G = torch.from_numpy(gen.standard_normal((B, L, 5)).astype(np.float32))
+    Gf = torch.from_numpy(gen.standard_normal((B, L, 1)).astype(np.float32))
+    lo, xo = logits.clone().requires_grad_(), x.clone().requires_grad_()
+    xn, fl = O.soft_step_from_logp(O.subs_parameterization(lo, xo), xo, u, mc_t, mc_s, temp, cft)
+    ((xn * G).sum() + (fl * Gf).sum()).backward()
+    lg, xg = logits.to(dev).requires_grad_(), x.to(dev).requires_grad_()
+    for inject in (True, False):
+        lg.grad = xg.grad = None
+        xn2, fl2 = autograd.soft_step_with_grad(lg, xg, mc_t.item(), mc_s.item(), temp, cft, 3, 9, 0,
+                                                u.to(dev) if inject else None)
+        ((xn2 * G.to(dev)).sum() + (fl2 * Gf.to(dev)).sum()).backward()
+        np.testing.assert_allclose(xn2.detach().cpu().numpy(), xn.detach().numpy(), rtol=1e-4, atol=2e-6)
+        np.testing.assert_allclose(fl2.detach().cpu().numpy(), fl.detach().numpy(), rtol=1e-5, atol=1e-6)
+        assert torch.isfinite(lg.grad).all() and torch.isfinite(xg.grad).all()
+        assert relerr(lg.grad.cpu(), lo.grad) < 1e-4, relerr(lg.grad.cpu(), lo.grad)
+        assert relerr(xg.grad.cpu(), xo.grad) < 1e-4
+        assert float(lg.grad[1].abs().max()) == 0.0          # rows holding a token: no gradient into the logits
+
+
+def _oracle_grads(sd, fn):
+    sdg = {k: v.clone().requires_grad_(k != 'backbone.time_embedder.0.W') for k, v in sd.items()}
+    loss = fn(sdg)
+    loss.backward()
+    return sdg
+
+
+def _check_param_grads(model, sdg, tol=GTOL):
+    worst = ('', 0.0)
+    for name, p in model.named_parameters():
+        ref = sdg[name].grad
+        if ref is None:
+            assert p.grad is None or not p.requires_grad
+            continue
+        assert p.grad is not None, name
+        e = relerr(p.grad.cpu(), ref)
+        worst = max(worst, (name, e), key=lambda t: t[1])
+        assert e < tol, (name, e)
+    return worst
+
+
+def _input_away_from_relu_kinks(sd, B, L, soft, sigma, first_seed):
+    """ReLU's derivative jumps at 0: an argument within rounding distance of 0 can get a different sign on the GPU
+    (accumulation order) and then a whole gradient term appears or disappears.  That is a property of the function,
+    not an error, so the unit test differentiates at an input whose ReLU arguments all clear the kink by 5e-6
+    (GPU and CPU pre-activations agree to ~1e-6)."""
+    for seed in range(first_seed, first_seed + 400):
+        gen = np.random.Generator(np.random.PCG64(seed))
+        x = torch.from_numpy(gen.dirichlet(np.ones(5) * 0.5, (B, L)).astype(np.float32)) if soft else \
+            torch.from_numpy(gen.integers(0, 5, (B, L)))
+        pre = []
+        with torch.no_grad():
+            O.cnn_forward(sd, x, sigma, preacts=pre)
+        if min(float(c.abs().min()) for c in pre) > 5e-6:
+            return x, gen
+    raise AssertionError('no input found away from the ReLU kinks')
+
+
+@pytest.mark.parametrize('soft,per_row_sigma', [(False, False), (True, True), (True, False)])
+def test_backbone_backward(dev, det_sd, soft, per_row_sigma):
+    B, L = 2, 45
+    m = drakes_amd.Diffusion(drakes_amd.default_config(length=L, time_conditioning=per_row_sigma)).to(dev)
+    m.load_state_dict(det_sd)
+    sigma = torch.tensor([0.3, 4.0]) if per_row_sigma else torch.zeros(B)
+    x, gen = _input_away_from_relu_kinks(det_sd, B, L, soft, sigma, 5)
+    Gm = torch.from_numpy(gen.standard_normal((B, L, 5)).astype(np.float32))
+    xo = x.clone().requires_grad_() if soft else x
+    sdg = _oracle_grads(det_sd, lambda sd: (O.cnn_forward(sd, xo, sigma) * Gm).sum())
+    xg = x.to(dev).requires_grad_() if soft else x.to(dev)
+    logits = m.backbone(xg, sigma.to(dev))
+    assert logits.requires_grad
+    (logits * Gm.to(dev)).sum().backward()
+    worst = _check_param_grads(m, sdg)
+    print('worst parameter gradient error:', worst)
+    if soft:
+        assert relerr(xg.grad.cpu(), xo.grad) < GTOL
+
+
+def test_forward_logp_with_grad_kl_term(gpu_model, dev, det_sd):
+    """Diffusion.forward under autograd, as the KL loop of fine_tune uses it (finetune_reward_bp.py:67-74)."""
+    gen = np.random.Generator(np.random.PCG64(6))
+    B, L = 2, 200
+    last_x = F.one_hot(torch.from_numpy(gen.integers(0, 5, (B, L))), 5).float()
+    condt = torch.full((B,), 0.69215769)
+    old = {k: v + 0.01 * torch.from_numpy(gen.standard_normal(tuple(v.shape)).astype(np.float32)) for k, v in det_sd.items()}
+    copy_flag = 1 - last_x[:, :, 4:5]
+    with torch.no_grad():
+        lp_old = O.model_forward(old, last_x, condt)
+    sdg = _oracle_grads(det_sd, lambda sd: O.kl_step(O.model_forward(sd, last_x, condt), lp_old, last_x, copy_flag, 0.5).mean())
+    gpu_model.zero_grad()
+    lp = gpu_model.forward(last_x.to(dev), condt.to(dev))
+    lpo, lx, cf = lp_old.to(dev), last_x.to(dev), copy_flag.to(dev)
+    p, po = lp[:, :, :-1].exp(), lpo[:, :, :-1].exp()
+    kl = (cf * (-p + po + p * (lp[:, :, :-1] - lpo[:, :, :-1])) / 0.5 * lx[:, :, :-1]).sum((1, 2)).mean()
+    kl.backward()
+    print('worst:', _check_param_grads(gpu_model, sdg))
+    gpu_model.zero_grad()
+
+
+@pytest.mark.parametrize('tag', ['s16k6', 's16k6_cft', 's128k50'])
+def test_sample_finetune_gradient_golden(dev, det_sd, tag):
+    g = load_golden(f'f5_finetune_{tag}.npz')
+    steps, trunc, temp, cft = int(g['steps']), int(g['trunc']), float(g['temp']), float(g['cft'])
+    cft = None if cft < 0 else cft
+    m = drakes_amd.Diffusion(drakes_amd.default_config(steps=steps)).to(dev)
+    m.load_state_dict(det_sd)
+    m.train()
+    m.config.finetuning.truncate_steps = trunc            # assigned by the caller, finetune_reward_bp.py:22-23
+    m.config.finetuning.gumbel_softmax_temp = temp
+    out, lx, ct, mct, cf = m._sample_finetune_gradient(eval_sp_size=2, copy_flag_temp=cft, seed=int(g['useed']))
+    assert out.shape == (2, 200, 4) and out.dtype == torch.float32 and out.requires_grad
+    assert len(lx) == len(ct) == len(mct) == len(cf) == steps
+    assert lx[0].shape == (2, 200, 5) and ct[0].shape == (2,) and mct[0].shape == (2, 1, 1) and cf[0].shape == (2, 200, 1)
+    assert cf[0].dtype == torch.int64 and cf[-1].dtype == torch.float32
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g['sample'], rtol=1e-4, atol=2e-4)
+    np.testing.assert_allclose(lx[-1].detach().cpu().numpy(), g['last_x_final'], rtol=1e-4, atol=2e-4)
+    np.testing.assert_allclose(cf[-1].detach().cpu().numpy(), g['copy_flag_final'], rtol=1e-4, atol=2e-4)
+    if 'last_x' in g.files:
+        np.testing.assert_allclose(torch.stack([t.detach() for t in lx]).cpu().numpy(), g['last_x'], rtol=1e-4, atol=2e-4)
+        assert np.array_equal(torch.stack(cf[:steps - trunc]).cpu().numpy(), g['copy_flag_hard'])
+        np.testing.assert_allclose(torch.stack(ct).cpu().numpy(), g['condt'], rtol=1e-6)
+        np.testing.assert_allclose(torch.stack(mct).cpu().numpy(), g['mc_t'], rtol=1e-6)
+    rw = torch.from_numpy(g['reward_w']).to(dev)
+    (-(out.permute(0, 2, 1) * rw).sum((1, 2)).mean()).backward()
+    params = dict(m.named_parameters())
+    for key in g.files:
+        if key.startswith('grad_backbone'):
+            name = key[len('grad_'):]
+            ref = torch.from_numpy(g[key])
+            got = params[name].grad.cpu()[:ref.shape[0]]
+            e = relerr(got, ref)
+            print(name, e)
+            assert e < 5e-3, (name, e)
+    gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m.parameters() if p.grad is not None)).item()
+    assert abs(gn - float(g['grad_norm'])) <= 2e-3 * float(g['grad_norm']), (gn, float(g['grad_norm']))
