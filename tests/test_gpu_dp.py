@@ -1,0 +1,27 @@
+"""Data-parallel layer on the real HIP path: two ranks share cuda:0 (gpurun boxes have one GPU; two RCCL ranks
+cannot share a device, so the collective runs over gloo on device tensors — dp.py is backend-agnostic)."""
+import pytest
+import torch
+
+from dp_launch import run_world
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize('hip_dtype', ['fp32', 'bf16'])
+def test_world2_matches_world1_on_gpu(tmp_path, hip_dtype):
+    extra = ['--global-batch', 5, '--grad-batch', 4, '--length', 200, '--steps', 16, '--trunc', 4, '--stacks', 4,
+             '--hip-dtype', hip_dtype]
+    one = run_world(1, 'gpu', str(tmp_path / 'w1'), extra)[0]
+    two = run_world(2, 'gpu', str(tmp_path / 'w2'), extra)
+    assert one['tokens'].shape == (5, 200) and int(one['tokens'].max()) <= 3
+    for r in two:
+        assert torch.equal(r['tokens'], one['tokens'])            # bit-exact: row j is keyed by its global index
+        assert r['views_ok']
+    assert torch.equal(torch.cat([r['mine'] for r in two]), one['tokens'])
+    assert torch.equal(two[0]['flat'], two[1]['flat'])
+    # gradients: fp32 atomics in the weight-gradient kernels make the summation order run-dependent
+    scale = float(one['flat'].abs().max())
+    assert float((two[0]['flat'] - one['flat']).abs().max()) <= 1e-4 * scale
+    assert abs(two[0]['norm'] - one['norm']) <= 1e-4 * one['norm']
