@@ -41,7 +41,8 @@ __global__ void __launch_bounds__(256) k_step_uniforms(float* __restrict__ u, lo
                                                        uint32_t step, uint64_t sample_offset) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     float uu[DRK_V];
-    drk_step_uniforms(seed, step, sample_offset + (uint64_t)(i / L), (uint32_t)(i % L), uu);
+    const uint32_t row = (uint32_t)i / (uint32_t)L;   // n < 2^32, checked by the entry point
+    drk_step_uniforms(seed, step, sample_offset + row, (uint32_t)i - row * (uint32_t)L, uu);
 #pragma unroll
     for (int k = 0; k < DRK_V; ++k) u[i * DRK_V + k] = uu[k];
   }
@@ -79,8 +80,11 @@ __global__ void __launch_bounds__(256)
       load5(logits, i, lg);
       if (INJECT)
         load5(uniforms, i, u);
-      else
-        drk_step_uniforms(seed, step, sample_offset + (uint64_t)(i / L), (uint32_t)(i % L), u);
+      else {
+        // n < 2^32 on every call the entry point accepts (B, L are ints): 32-bit divide, not the 64-bit one
+        const uint32_t row = (uint32_t)i / (uint32_t)L;
+        drk_step_uniforms(seed, step, sample_offset + row, (uint32_t)i - row * (uint32_t)L, u);
+      }
       drk_subs_logp(lg, DRK_MASK, lp);
       drk_posterior(lp, mc_t, mc_s, q);
       out = drk_gumbel_argmax(q, u);
@@ -118,6 +122,7 @@ extern "C" int drk_step_uniforms(float* u, int B, int L, uint64_t seed, uint32_t
   if (!u || B < 0 || L <= 0) return drk_set_error_msg(DRK_EINVAL, "drk_step_uniforms: bad arguments");
   const long n = (long)B * L;
   if (n == 0) return DRK_OK;
+  if (n >= (1L << 32)) return drk_set_error_msg(DRK_EINVAL, "drk_step_uniforms: B*L must be below 2^32");
   hipLaunchKernelGGL(k_step_uniforms, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, u, n, L, seed, step,
                      sample_offset);
   DRK_CHECK_LAUNCH();
@@ -144,6 +149,7 @@ extern "C" int drk_reverse_step_hard(const float* logits, const int64_t* x, cons
     return drk_set_error_msg(DRK_EINVAL, "drk_reverse_step_hard: bad arguments");
   const long n = (long)B * L;
   if (n == 0) return DRK_OK;
+  if (n >= (1L << 32)) return drk_set_error_msg(DRK_EINVAL, "drk_reverse_step_hard: B*L must be below 2^32");
   if (uniforms)
     hipLaunchKernelGGL(k_reverse_step_hard<true>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, logits, x,
                        uniforms, x_next, n, L, mc_t, mc_s, seed, step, sample_offset);

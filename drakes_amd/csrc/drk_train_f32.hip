@@ -394,7 +394,8 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
       for (int v = 0; v < DRK_V; ++v) u[v] = uniforms[i * DRK_V + v];
     } else {
-      drk_step_uniforms(seed, step, sample_offset + (uint64_t)(i / L), (uint32_t)(i % L), u);
+      const uint32_t row = (uint32_t)i / (uint32_t)L;   // B*L < 2^32, checked by the entry point
+      drk_step_uniforms(seed, step, sample_offset + row, (uint32_t)i - row * (uint32_t)L, u);
     }
     soft_row(lg, xs, u, mc_t, mc_s, inv_temp, cft, tok, lp, y, flag);
 #pragma unroll
@@ -424,7 +425,8 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
       for (int v = 0; v < DRK_V; ++v) u[v] = uniforms[i * DRK_V + v];
     } else {
-      drk_step_uniforms(seed, step, sample_offset + (uint64_t)(i / L), (uint32_t)(i % L), u);
+      const uint32_t row = (uint32_t)i / (uint32_t)L;   // B*L < 2^32, checked by the entry point
+      drk_step_uniforms(seed, step, sample_offset + row, (uint32_t)i - row * (uint32_t)L, u);
     }
     soft_row(lg, xs, u, mc_t, mc_s, inv_temp, cft, tok, lp, y, flag);
     float dflag = gflag ? gflag[i] : 0.f;
@@ -558,6 +560,7 @@ extern "C" int drk_reverse_step_soft_fwd(const float* logits, const float* x_sof
   DRK_SHAPE_GUARD("drk_reverse_step_soft_fwd");
   ARGCHECK(logits && x_soft && x_next && flag && temp > 0.f, "drk_reverse_step_soft_fwd");
   const long n = (long)B * L;
+  ARGCHECK(n < (1L << 32), "drk_reverse_step_soft_fwd (B*L must be below 2^32)");
   if (uniforms)
     hipLaunchKernelGGL(k_soft_step_fwd<true>, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, logits, x_soft,
                        uniforms, x_next, flag, n, L, mc_t, mc_s, 1.0f / temp, copy_flag_temp, seed, step, sample_offset);
@@ -575,6 +578,7 @@ extern "C" int drk_reverse_step_soft_bwd(const float* logits, const float* x_sof
   DRK_SHAPE_GUARD("drk_reverse_step_soft_bwd");
   ARGCHECK(logits && x_soft && grad_x_next && dlogits && dx && temp > 0.f, "drk_reverse_step_soft_bwd");
   const long n = (long)B * L;
+  ARGCHECK(n < (1L << 32), "drk_reverse_step_soft_bwd (B*L must be below 2^32)");
   if (uniforms)
     hipLaunchKernelGGL(k_soft_step_bwd<true>, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, logits, x_soft,
                        uniforms, grad_x_next, grad_flag, dlogits, dx, n, L, mc_t, mc_s, 1.0f / temp, copy_flag_temp, seed,

@@ -113,7 +113,12 @@ class GradBucket:
         """Sum over ranks, divide by the world size.  No-op at world size 1."""
         w = world()
         if w > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            if dist.get_backend() == 'nccl' or self.flat.device.type == 'cpu':
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)          # RCCL ring over xGMI
+            else:                       # gloo rehearsal with device tensors (tests): stage on the host
+                host = self.flat.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM)
+                self.flat.copy_(host)
             self.flat.mul_(1.0 / w)
         return self.flat
 
