@@ -131,7 +131,7 @@ def main():
                          'traffic': None, 'launches_timed': n_timed, 'avg_launch_ms': avg_ms,
                          'flop_per_launch': flop_per_launch},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # rank 0, N=1 only
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:
