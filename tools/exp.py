@@ -6,7 +6,8 @@
 """
 import os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
+# DRK_PKG_ROOT=_ab_old: import the snapshot of an older package (its own library and packing) for A/B timing in one call
+sys.path.insert(0, os.path.join(ROOT, os.environ['DRK_PKG_ROOT']) if os.environ.get('DRK_PKG_ROOT') else ROOT)
 
 def build(name, flags):
     from drakes_amd import build as b
