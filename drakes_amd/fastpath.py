@@ -2,10 +2,10 @@
 loop, drakes_amd/csrc/drk_sample_bf16.hip) and launches it.
 
 Weight stream layout (MFMA-fragment order, read straight from L2 into registers):
-    tap = [8 k-steps][4 co tiles][64 lanes][8 bf16] = 32 KB (see _frag_tap);
+    tap = [4 k-steps][4 co tiles][2 row tiles][64 lanes][8 bf16] = 32 KB (see _frag_tap);
     order = for each layer its 9 taps, then final_conv.0.
-The stem ([128][64] bf16, col 5*tap+v) and final_conv.2 ([8][128] bf16, rows 0..4) are small and stay
-resident in LDS for the whole launch.
+The stem (a [46][128] bf16 gather table, row 5*tap+v) and final_conv.2 ([8][128] bf16, rows 0..4) are small
+and stay resident in LDS for the whole launch.
 """
 import ctypes
 
@@ -17,20 +17,11 @@ MAX_L = 224
 
 
 def _frag_tap(m):
-    """[128 co][128 ci] float -> bf16 [8 k-steps][4 co tiles][64 lanes][8]: lane (lr, half) of the wave that owns
-    co tile ct holds, for k-step ks, W[32ct + lr][16ks + 8half + 0..7] (the A operand of v_mfma_f32_32x32x16_bf16)."""
-    w = m.to(torch.bfloat16).reshape(4, 32, 8, 2, 8)      # [ct][lr][ks][half][j]
-    return w.permute(2, 0, 3, 1, 4).contiguous().reshape(8, 4, 64, 8)
-
-
-def _swizzle_stage(m):
-    """[128][128] float -> bf16 with chunk c of row r stored at chunk c ^ (r & 15)."""
-    r = torch.arange(128, device=m.device)[:, None]
-    c = torch.arange(128, device=m.device)[None, :]
-    dest = (((c >> 3) ^ (r & 15)) << 3) | (c & 7)
-    out = torch.empty(128, 128, dtype=torch.bfloat16, device=m.device)
-    out.scatter_(1, dest.expand(128, 128), m.to(torch.bfloat16))
-    return out
+    """[128 co][128 ci] float -> bf16 [4 k-steps][4 co tiles][2 row tiles][64 lanes][8]: lane 16g + n of the wave that
+    owns co tile ct holds, for k-step ks and row tile s, W[32ct + 16s + n][64(g&1) + 32(g>>1) + 8ks + 0..7] — the A
+    operand of v_mfma_f32_16x16x32_bf16 with the kernel's k-slot <-> channel map (drk_sample_bf16.hip, header)."""
+    w = m.to(torch.bfloat16).reshape(4, 2, 16, 2, 2, 4, 8)     # [ct][s][n][g&1][g>>1][ks][j]
+    return w.permute(5, 0, 1, 4, 3, 2, 6).contiguous().reshape(4, 4, 2, 64, 8)
 
 
 def pack_stream(bb):
@@ -39,9 +30,9 @@ def pack_stream(bb):
     n = bb.num_layers
     with torch.no_grad():
         stages = []
-        stem = torch.zeros(128, 64, device=dev)
-        # linear.weight [co][v][tap] -> col 5*tap + v (LDS-resident, plain [128][64] bf16)
-        stem[:, :45] = bb.linear.weight.permute(0, 2, 1).reshape(128, 45)
+        stem = torch.zeros(46, 128, device=dev)
+        # linear.weight [co][v][tap] -> row 5*tap + v of a gather table (LDS-resident); row 45 stays zero
+        stem[:45] = bb.linear.weight.permute(2, 1, 0).reshape(45, 128)
         for i in range(n):
             w = bb.convs[i].weight          # [co][ci][tap]
             for t in range(9):
