@@ -340,6 +340,7 @@ __device__ __forceinline__ void sample_body(const SampleArgs& a, char* smem, int
 #ifdef DRK_STAMPS
   unsigned long long tacc[4] = {0, 0, 0, 0}, t0;
   STAMP(t0);
+  const unsigned long long clk0 = t0, rt0 = __builtin_amdgcn_s_memrealtime();   // shader cycles vs the 100 MHz counter
 #endif
   const int n_fwd = a.num_steps + (a.noise_removal ? 1 : 0);
   for (int f = 0; f < n_fwd; ++f) {
@@ -524,7 +525,9 @@ __device__ __forceinline__ void sample_body(const SampleArgs& a, char* smem, int
 #ifdef DRK_STAMPS
   if (a.dbg_feat && lane == 0) {
     unsigned long long* o = (unsigned long long*)a.dbg_feat + (b * 8 + wave) * 4;
-    o[0] = tacc[0]; o[1] = tacc[1]; o[2] = tacc[2]; o[3] = tacc[3];
+    o[0] = tacc[0]; o[1] = __builtin_amdgcn_s_memtime() - clk0; o[2] = tacc[2]; o[3] = tacc[3];
+    tacc[1] = __builtin_amdgcn_s_memrealtime() - rt0;
+    if (wave == 0) ((unsigned long long*)a.dbg_feat)[(long)a.B * 32 + b] = tacc[1];   // 100 MHz ticks of this workgroup
   }
 #endif
   if (tid < L) a.x_out[b * L + tid] = tok[tid];

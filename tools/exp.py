@@ -52,7 +52,12 @@ def stamps(B=1024, steps=8):
     dbg = torch.zeros(B * 200 * 128, dtype=torch.float32, device=dev)
     fastpath._launch(bb, tbias, 0, mc, None, None, out, None, -1, B, 200, steps, True, 5, 0, dbg, -2)
     torch.cuda.synchronize()
-    st = dbg.view(torch.int64)[: B * 8 * 4].reshape(B, 8, 4).cpu().numpy().astype(np.float64)
+    raw = dbg.view(torch.int64)
+    st = raw[: B * 8 * 4].reshape(B, 8, 4).cpu().numpy().astype(np.float64)
+    ticks = raw[B * 32: B * 32 + B].cpu().numpy().astype(np.float64)          # 100 MHz
+    cyc = st[:, 0, 1].copy()                                                   # shader cycles of wave 0 over the same span
+    print(f'in-kernel clock: {np.median(cyc / ticks) * 0.1:.3f} GHz (median over workgroups; min {np.min(cyc / ticks) * 0.1:.3f}, max {np.max(cyc / ticks) * 0.1:.3f})')
+    st[:, :, 1] = 0
     tot = st.sum(-1, keepdims=True)
     sh = st / tot
     names = ['mma', 'stage sync', 'layer epilogue+LN', 'stem/head/step']
