@@ -7,5 +7,7 @@ the first kernel call does, and raises if it has not been built.
 """
 from .diffusion import Diffusion  # noqa: F401
 from .config import default_config  # noqa: F401
+from .finetune_loop import fine_tune  # noqa: F401
+from ._lib import DrakesHipError  # noqa: F401
 
-__all__ = ['Diffusion', 'default_config']
+__all__ = ['Diffusion', 'default_config', 'fine_tune', 'DrakesHipError']

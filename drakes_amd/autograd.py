@@ -62,14 +62,17 @@ class _BackboneFn(torch.autograd.Function):
         nb = ctx.sigma.shape[0]
         dlogits = dlogits.contiguous()
         g = {}
+        want_w = any(ctx.needs_input_grad[3:])     # a frozen model (the KL reference model) only passes the input gradient on
         # head
         dy = torch.empty_like(y)
         dw2, db2 = _zeros(V, C, like=y), _zeros(V, like=y)
         ops.head_out_bwd(dlogits, y, pk['head2_w'], dy, dw2, db2)
         dpre = ops.relu_bwd(dy, y, out=dy)
         dw0 = _zeros(1, C, C, like=y)
-        ops.conv_wgrad_f32(feats[n], dpre, dw0, 0)
-        db0 = ops.colsum128(dpre, 1, M, _zeros(1, C, like=y))
+        db0 = _zeros(1, C, like=y)
+        if want_w:
+            ops.conv_wgrad_f32(feats[n], dpre, dw0, 0)
+            ops.colsum128(dpre, 1, M, db0)
         gr = ops.conv_fwd_f32(dpre, pk['head0_wT'], None, None, 0, relu=False)
         g['final_conv.2.weight'], g['final_conv.2.bias'] = dw2.unsqueeze(-1), db2
         g['final_conv.0.weight'], g['final_conv.0.bias'] = dw0.permute(2, 1, 0), db0[0]
@@ -82,25 +85,29 @@ class _BackboneFn(torch.autograd.Function):
         for i in reversed(range(n)):
             d = bb.dilation(i)
             ops.mask_mul(gr, masks[i], out=dc)
-            g[f'convs.{i}.bias'] = ops.colsum128(dc, 1, M, _zeros(1, C, like=y))[0]
-            ops.ln_fwd(feats[i], ctx.tbias[0, i], ctx.tb_stride, pk['ln_g'][i], pk['ln_b'][i], out=h)
-            dwt = _zeros(9, C, C, like=y)
-            ops.conv_wgrad_f32(h, dc, dwt, d)
-            g[f'convs.{i}.weight'] = dwt.permute(2, 1, 0)
+            if want_w:
+                g[f'convs.{i}.bias'] = ops.colsum128(dc, 1, M, _zeros(1, C, like=y))[0]
+                ops.ln_fwd(feats[i], ctx.tbias[0, i], ctx.tb_stride, pk['ln_g'][i], pk['ln_b'][i], out=h)
+                dwt = _zeros(9, C, C, like=y)
+                ops.conv_wgrad_f32(h, dc, dwt, d)
+                g[f'convs.{i}.weight'] = dwt.permute(2, 1, 0)
             ops.conv_fwd_f32(dc, pk['conv_wT'][i], None, None, d, relu=False, out=dh)
             dgam, dbet = _zeros(C, like=y), _zeros(C, like=y)
             gnew = torch.empty_like(y)
             ops.ln_bwd(dh, feats[i], ctx.tbias[0, i], ctx.tb_stride, pk['ln_g'][i], means[i], rstds[i], gr, dxin, gnew,
                        dgam, dbet)
             g[f'norms.{i}.weight'], g[f'norms.{i}.bias'] = dgam, dbet
-            if ctx.tb_stride:
+            if not want_w:
+                pass
+            elif ctx.tb_stride:
                 ops.colsum128(dxin, B, L, dtb[i])
             else:
                 ops.colsum128(dxin, 1, M, dtb[i])
             gr = gnew
         # stem
         dpre = ops.relu_bwd(gr, feats[0], out=gr)
-        g['linear.bias'] = ops.colsum128(dpre, 1, M, _zeros(1, C, like=y))[0]
+        if want_w:
+            g['linear.bias'] = ops.colsum128(dpre, 1, M, _zeros(1, C, like=y))[0]
         dw_t = _zeros(9, V, C, like=y)
         dseq = None
         if seq.dtype != torch.int64:
@@ -110,8 +117,9 @@ class _BackboneFn(torch.autograd.Function):
         # time path
         d_dense_w, d_dense_b = _zeros(n, C, C, like=y), _zeros(n, C, like=y)
         d_lin_w, d_lin_b = _zeros(C, C, like=y), _zeros(C, like=y)
-        ops.time_bwd(dtb.permute(1, 0, 2).contiguous(), ctx.sigma, pk['four_W'], ctx.temb, pk['dense_w'], d_dense_w,
-                     d_dense_b, d_lin_w, d_lin_b)
+        if want_w:
+            ops.time_bwd(dtb.permute(1, 0, 2).contiguous(), ctx.sigma, pk['four_W'], ctx.temb, pk['dense_w'], d_dense_w,
+                         d_dense_b, d_lin_w, d_lin_b)
         g['time_embedder.1.weight'], g['time_embedder.1.bias'] = d_lin_w, d_lin_b
         for i in range(n):
             g[f'time_layers.{i}.dense.weight'], g[f'time_layers.{i}.dense.bias'] = d_dense_w[i], d_dense_b[i]
@@ -163,3 +171,30 @@ class _SoftStepFn(torch.autograd.Function):
 
 def soft_step_with_grad(logits, x_soft, mc_t, mc_s, temp, cft, seed, step, sample_offset, uniforms):
     return _SoftStepFn.apply(logits, x_soft, mc_t, mc_s, temp, cft, seed, step, sample_offset, uniforms)
+
+
+class _KLStepFn(torch.autograd.Function):
+    """kl[b] of one reverse step (finetune_reward_bp.py:67-74).  Differentiable w.r.t. logp and, on soft steps,
+    last_x, copy_flag (both carry a graph there, diffusion_gosai_update.py:580-586) and logp_old (a function of last_x
+    through the frozen model, finetune_reward_bp.py:68)."""
+
+    @staticmethod
+    def forward(ctx, logp, logp_old, last_x, flag, mc_t):
+        logp, logp_old, last_x, flag = logp.contiguous(), logp_old.contiguous(), last_x.contiguous(), flag.contiguous()
+        ctx.save_for_backward(logp, logp_old, last_x, flag)
+        ctx.mc_t = mc_t
+        ctx.flag_shape = flag.shape
+        return ops.kl_step_fwd(logp, logp_old, last_x, flag, mc_t)
+
+    @staticmethod
+    def backward(ctx, g):
+        logp, logp_old, last_x, flag = ctx.saved_tensors
+        want_old, want_dx = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        want_df = ctx.needs_input_grad[3] and flag.dtype == torch.float32
+        dlogp, dold, dx, dflag = ops.kl_step_bwd(logp, logp_old, last_x, flag, g.contiguous(), ctx.mc_t, want_old, want_dx,
+                                                 want_df)
+        return dlogp, dold, dx, (dflag.reshape(ctx.flag_shape) if dflag is not None else None), None
+
+
+def kl_step_with_grad(logp, logp_old, last_x, flag, mc_t):
+    return _KLStepFn.apply(logp, logp_old, last_x, flag, float(mc_t))

@@ -452,6 +452,65 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// ---- per-step KL term of the fine-tune loss (finetune_reward_bp.py:67-74) ---------------------------
+//   kl[b] = sum_{l, v<4} flag[b,l] * (-p + p_old + p * (lp - lp_old)) / mc_t * last_x[b,l,v],  p = exp(lp)
+// One workgroup per batch row (deterministic reduction order).  flag is int64 (hard steps) or float (soft steps).
+__device__ __forceinline__ float kl_flag(const float* ff, const int64_t* fi, long i) { return ff ? ff[i] : (float)fi[i]; }
+
+__global__ void __launch_bounds__(256) k_kl_fwd(const float* __restrict__ lp, const float* __restrict__ lpo,
+                                                const float* __restrict__ x, const float* __restrict__ ff,
+                                                const int64_t* __restrict__ fi, float inv_mc, float* __restrict__ kl, int L) {
+  const long b = blockIdx.x;
+  float acc = 0.f;
+  for (int l = threadIdx.x; l < L; l += 256) {
+    const long i = b * L + l;
+    const float cf = kl_flag(ff, fi, i);
+    float s = 0.f;
+#pragma unroll
+    for (int v = 0; v < DRK_V - 1; ++v) {
+      const float a = lp[i * DRK_V + v], o = lpo[i * DRK_V + v];
+      const float p = expf(a), po = expf(o);
+      s += (cf * (-p + po + p * (a - o)) * inv_mc) * x[i * DRK_V + v];
+    }
+    acc += s;
+  }
+  __shared__ float red[256];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) kl[b] = red[0];
+}
+
+// d kl[b] / d lp, d lp_old, d last_x, d flag, scaled by g[b]; dlpo / dx / dflag may be NULL (hard steps: constants).
+__global__ void __launch_bounds__(256) k_kl_bwd(const float* __restrict__ lp, const float* __restrict__ lpo,
+                                                const float* __restrict__ x, const float* __restrict__ ff,
+                                                const int64_t* __restrict__ fi, const float* __restrict__ g, float inv_mc,
+                                                float* __restrict__ dlp, float* __restrict__ dlpo, float* __restrict__ dx,
+                                                float* __restrict__ dflag, long n, int L) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float gb = g[i / L] * inv_mc;
+    const float cf = kl_flag(ff, fi, i);
+    float df = 0.f;
+#pragma unroll
+    for (int v = 0; v < DRK_V - 1; ++v) {
+      const float a = lp[i * DRK_V + v], o = lpo[i * DRK_V + v], xv = x[i * DRK_V + v];
+      const float p = expf(a), po = expf(o);
+      const float term = -p + po + p * (a - o);
+      dlp[i * DRK_V + v] = gb * cf * xv * (p * (a - o));
+      if (dlpo) dlpo[i * DRK_V + v] = gb * cf * xv * (po - p);
+      if (dx) dx[i * DRK_V + v] = gb * cf * term;
+      df += term * xv;
+    }
+    dlp[i * DRK_V + DRK_MASK] = 0.f;
+    if (dlpo) dlpo[i * DRK_V + DRK_MASK] = 0.f;
+    if (dx) dx[i * DRK_V + DRK_MASK] = 0.f;
+    if (dflag) dflag[i] = gb * df;
+  }
+}
+
 // ------------------------------------------------------------------------------------ C ABI
 extern "C" int drk_mask_mul(const float* g, const unsigned char* mask, float* out, long n, void* stream) {
   ARGCHECK(n >= 0 && (n % 4) == 0, "drk_mask_mul");
@@ -587,6 +646,28 @@ extern "C" int drk_reverse_step_soft_bwd(const float* logits, const float* x_sof
     hipLaunchKernelGGL(k_soft_step_bwd<false>, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, logits, x_soft,
                        uniforms, grad_x_next, grad_flag, dlogits, dx, n, L, mc_t, mc_s, 1.0f / temp, copy_flag_temp, seed,
                        step, sample_offset);
+  DRK_CHECK_LAUNCH();
+  return DRK_OK;
+}
+
+extern "C" int drk_kl_step_fwd(const float* logp, const float* logp_old, const float* last_x, const float* flag_f,
+                               const int64_t* flag_i, float move_chance_t, float* kl, int B, int L, void* stream) {
+  DRK_SHAPE_GUARD("drk_kl_step_fwd");
+  ARGCHECK(logp && logp_old && last_x && (flag_f || flag_i) && kl && move_chance_t > 0.f, "drk_kl_step_fwd");
+  hipLaunchKernelGGL(k_kl_fwd, dim3(B), dim3(256), 0, (hipStream_t)stream, logp, logp_old, last_x, flag_f, flag_i,
+                     1.0f / move_chance_t, kl, L);
+  DRK_CHECK_LAUNCH();
+  return DRK_OK;
+}
+
+extern "C" int drk_kl_step_bwd(const float* logp, const float* logp_old, const float* last_x, const float* flag_f,
+                               const int64_t* flag_i, const float* grad_kl, float move_chance_t, float* dlogp,
+                               float* dlogp_old, float* dlast_x, float* dflag, int B, int L, void* stream) {
+  DRK_SHAPE_GUARD("drk_kl_step_bwd");
+  ARGCHECK(logp && logp_old && last_x && (flag_f || flag_i) && grad_kl && dlogp && move_chance_t > 0.f, "drk_kl_step_bwd");
+  const long n = (long)B * L;
+  hipLaunchKernelGGL(k_kl_bwd, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, logp, logp_old, last_x, flag_f,
+                     flag_i, grad_kl, 1.0f / move_chance_t, dlogp, dlogp_old, dlast_x, dflag, n, L);
   DRK_CHECK_LAUNCH();
   return DRK_OK;
 }

@@ -1,0 +1,134 @@
+"""The DRAKES fine-tune loop on the HIP path: `fine_tune` of the reference
+(/root/reference/drakes_dna/finetune_reward_bp.py:17-123) — reward back-propagated through the last K Gumbel-softmax
+reverse steps plus a per-step KL term against the frozen pre-trained model, gradient accumulation, clipping, Adam.
+
+Same arguments and return value as the reference function.  Differences, all additive:
+  * the reference reads the module globals `log_path` / `save_path` and logs to wandb; here they are keyword
+    arguments (None = no file output) and there is no wandb;
+  * `seed_of_call(i)` fixes the Philox seed of the i-th `_sample_finetune_gradient` call (default: drawn from torch's
+    generator, so torch.manual_seed reproduces a run);
+  * `old_model`'s parameters are frozen (requires_grad False) for the duration of the call: the reference accumulates
+    gradients on them that nothing reads; the gradient THROUGH the old model into last_x is kept (:68);
+  * `on_update(model, epoch)` is called before every optimizer step with the reduced, unclipped gradients in
+    place (tests, logging);
+  * under torch.distributed (drakes_amd.dp) every rank runs its own shard (`args.batch_size` rows per rank); the flat
+    gradient bucket is all-reduced once, after the last accumulation micro-step and BEFORE clipping (:89-92).
+The reward models are the caller's torch modules (the gReLU model in the reference, oracle.py:230-262): outside the
+path, called as they are.
+"""
+import os
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import autograd, dp
+
+
+def kl_of_step(new_model, old_model, last_x, condt, move_chance_t, copy_flag):
+    """kl_div [B] of one recorded reverse step — finetune_reward_bp.py:63-74, one fused kernel each way.
+
+    On soft steps last_x carries the sampling graph, so the reference's gradient also runs back through
+    old_model.forward(last_x) (:68) into the chain; the frozen model then passes only its input gradient on.  On hard
+    steps last_x is a constant and the frozen model runs without a graph."""
+    log_p_x0 = new_model.forward(last_x, condt)
+    if last_x.requires_grad:
+        log_p_x0_old = old_model.forward(last_x, condt)
+    else:
+        with torch.no_grad():
+            log_p_x0_old = old_model.forward(last_x, condt)
+    return autograd.kl_step_with_grad(log_p_x0, log_p_x0_old, last_x, copy_flag, float(move_chance_t.reshape(-1)[0]))
+
+
+def fine_tune(new_model, new_model_y, new_model_y_eval, old_model, args, eps=1e-5, *, log_path=None, save_path=None,
+              seed_of_call=None, verbose=True, on_update=None):
+    if log_path is not None:
+        with open(log_path, 'w') as f:
+            f.write(args.__repr__() + '\n')
+
+    new_model.config.finetuning.truncate_steps = args.truncate_steps                          # :22-23
+    new_model.config.finetuning.gumbel_softmax_temp = args.gumbel_temp
+    new_model.train()
+    torch.set_grad_enabled(True)
+    old_flags = [p.requires_grad for p in old_model.parameters()]
+    for p in old_model.parameters():
+        p.requires_grad_(False)
+    optim = torch.optim.Adam(new_model.parameters(), lr=args.learning_rate)                   # :27
+    bucket = dp.GradBucket(new_model)           # every .grad is a view of one flat fp32 buffer (one all-reduce, one norm)
+    bucket.zero_()
+    batch_losses = []
+    batch_rewards = []
+    call = 0
+    rank, world = dp.rank(), dp.world()
+
+    for epoch_num in range(args.num_epochs):                                                  # :31
+        rewards, rewards_eval, losses, reward_losses, kl_losses = [], [], [], [], []
+        tot_grad_norm = 0.0
+        new_model.train()
+        for _step in range(args.num_accum_steps):                                             # :39
+            kw = {}
+            if seed_of_call is not None:
+                kw['seed'] = seed_of_call(call)
+            call += 1
+            sample, last_x_list, condt_list, move_chance_t_list, copy_flag_list = new_model._sample_finetune_gradient(
+                eval_sp_size=args.batch_size, copy_flag_temp=args.copy_flag_temp,
+                sample_offset=rank * args.batch_size, **kw)                                   # :40, [bsz, seqlen, 4]
+            sample2 = torch.transpose(sample, 1, 2)
+            preds = new_model_y(sample2).squeeze(-1)                                          # [bsz, 3]
+            reward = preds[:, 0]
+
+            with torch.no_grad():                                                             # logging only (:45-55)
+                sample_argmax = 1.0 * F.one_hot(torch.argmax(sample, 2), num_classes=4)
+                sample_argmax = torch.transpose(sample_argmax, 1, 2)
+                rewards.append(new_model_y(sample_argmax).squeeze(-1)[:, 0].cpu().numpy())
+                rewards_eval.append(new_model_y_eval(sample_argmax).squeeze(-1)[:, 0].cpu().numpy())
+
+            total_kl = []
+            for random_t in range(args.total_num_steps):                                      # :60-75
+                if args.truncate_kl and random_t < args.total_num_steps - args.truncate_steps:
+                    continue
+                total_kl.append(kl_of_step(new_model, old_model, last_x_list[random_t], condt_list[random_t],
+                                           move_chance_t_list[random_t], copy_flag_list[random_t]))
+
+            if epoch_num < args.alpha_schedule_warmup:                                        # :77-81, linear warm-up
+                current_alpha = (epoch_num + 1) / args.alpha_schedule_warmup * args.alpha
+            else:
+                current_alpha = args.alpha
+
+            kl_loss = torch.stack(total_kl, 1).sum(1).mean()                                  # :83-86
+            reward_loss = -torch.mean(reward)
+            loss = reward_loss + kl_loss * current_alpha
+            loss = loss / args.num_accum_steps
+
+            loss.backward()
+            if (_step + 1) % args.num_accum_steps == 0:                                       # :89-93
+                bucket.allreduce_mean_()
+                if on_update is not None:
+                    on_update(new_model, epoch_num)
+                norm = bucket.clip_grad_norm_(args.gradnorm_clip)
+                tot_grad_norm += float(norm)
+                optim.step()
+                bucket.zero_()                  # optim.zero_grad() would drop the views
+
+            batch_losses.append(loss.cpu().detach().numpy())
+            batch_rewards.append(torch.mean(reward).cpu().detach().numpy())
+            losses.append(loss.cpu().detach().numpy() * args.num_accum_steps)
+            reward_losses.append(reward_loss.cpu().detach().numpy())
+            kl_losses.append(kl_loss.cpu().detach().numpy())
+
+        rewards, rewards_eval = np.array(rewards), np.array(rewards_eval)
+        line = (f'Epoch {epoch_num} Mean reward {np.mean(rewards)} Mean reward eval {np.mean(rewards_eval)} '
+                f'Mean grad norm {tot_grad_norm} Mean loss {np.mean(losses)} Mean reward loss {np.mean(reward_losses)} '
+                f'Mean kl loss {np.mean(kl_losses)}')
+        if verbose and rank == 0:
+            print(line, flush=True)
+        if log_path is not None and rank == 0:
+            with open(log_path, 'a') as f:
+                f.write(line + '\n')
+        if save_path is not None and rank == 0 and (epoch_num + 1) % args.save_every_n_epochs == 0:   # :115-118
+            torch.save(new_model.state_dict(), os.path.join(save_path, f'model_{epoch_num}.ckpt'))
+    for p, f in zip(old_model.parameters(), old_flags):
+        p.requires_grad_(f)
+    fine_tune.last_log = dict(tot_grad_norm=tot_grad_norm, mean_reward=float(np.mean(rewards)),
+                              mean_kl=float(np.mean(kl_losses)))
+    return batch_losses

@@ -275,3 +275,33 @@ def pack_conv_weight_f32(w):
 def pack_stem_weight(w):
     """[co][5][9] -> [9][5][co]."""
     return w.detach().permute(2, 1, 0).contiguous()
+
+
+# ---- fine-tune loss: per-step KL term ----------------------------------------------------------
+def _flag_ptrs(flag):
+    """copy_flag [B,L] or [B,L,1]: float32 (soft steps) or int64 (hard steps) -> (float ptr, int64 ptr)."""
+    if flag.dtype == torch.int64:
+        return None, _i(flag, 'copy_flag')
+    return _f(flag, 'copy_flag'), None
+
+
+def kl_step_fwd(logp, logp_old, last_x, flag, mc_t):
+    B, L, _ = logp.shape
+    kl = torch.empty(B, dtype=torch.float32, device=logp.device)
+    ff, fi = _flag_ptrs(flag)
+    _lib.call('drk_kl_step_fwd', _f(logp, 'logp'), _f(logp_old, 'logp_old'), _f(last_x, 'last_x'), ff, fi, float(mc_t),
+              _f(kl, 'kl'), B, L, _stream())
+    return kl
+
+
+def kl_step_bwd(logp, logp_old, last_x, flag, grad_kl, mc_t, want_dold, want_dx, want_dflag):
+    B, L, _ = logp.shape
+    dlogp = torch.empty_like(logp)
+    dold = torch.empty_like(logp) if want_dold else None
+    dx = torch.empty_like(last_x) if want_dx else None
+    dflag = torch.empty(B, L, dtype=torch.float32, device=logp.device) if want_dflag else None
+    ff, fi = _flag_ptrs(flag)
+    _lib.call('drk_kl_step_bwd', _f(logp, 'logp'), _f(logp_old, 'logp_old'), _f(last_x, 'last_x'), ff, fi,
+              _f(grad_kl, 'grad_kl'), float(mc_t), _f(dlogp, 'dlogp'), _f(dold, 'dlogp_old'), _f(dx, 'dlast_x'),
+              _f(dflag, 'dflag'), B, L, _stream())
+    return dlogp, dold, dx, dflag

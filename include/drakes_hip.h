@@ -140,6 +140,20 @@ int drk_reverse_step_soft_bwd(const float* logits, const float* x_soft, const fl
                               int L, float mc_t, float mc_s, float temp, float copy_flag_temp, uint64_t seed,
                               uint32_t step, uint64_t sample_offset, void* stream);
 
+/* ---- fine-tune loss: per-step KL term (caller of the path) ------------------------
+ * kl[b] = sum_{l, v<4} flag[b,l] * (-p + p_old + p*(lp - lp_old)) / move_chance_t * last_x[b,l,v], p = exp(lp):
+ * finetune_reward_bp.py:67-74 (`kl_div` of one reverse step; the caller sums the steps, :83).  logp, logp_old,
+ * last_x float32 [B][L][5] (column 4 unused); flag = copy_flag [B][L], float32 (soft steps) or int64 (hard steps),
+ * exactly one of the two pointers non-NULL; kl float32 [B]. */
+int drk_kl_step_fwd(const float* logp, const float* logp_old, const float* last_x, const float* flag_f,
+                    const int64_t* flag_i, float move_chance_t, float* kl, int B, int L, void* stream);
+/* Gradients of sum_b grad_kl[b] * kl[b]: dlogp [B][L][5] (column 4 = 0) always; dlogp_old [B][L][5], dlast_x [B][L][5]
+ * and dflag [B][L] when non-NULL (soft steps, where last_x and copy_flag carry a graph,
+ * diffusion_gosai_update.py:580-586, and through last_x so does old_model.forward(last_x), finetune_reward_bp.py:68). */
+int drk_kl_step_bwd(const float* logp, const float* logp_old, const float* last_x, const float* flag_f,
+                    const int64_t* flag_i, const float* grad_kl, float move_chance_t, float* dlogp, float* dlogp_old,
+                    float* dlast_x, float* dflag, int B, int L, void* stream);
+
 /* ---- fused sampling loop, bf16 MFMA ----------------------------------------------------------- */
 /* The whole of Diffusion._sample (diffusion_gosai_update.py:506-550, ddpm predictor) in one launch:
  * num_steps x (CNNModel.forward + _subs_parameterization + _ddpm_update tail) and, if
