@@ -67,3 +67,18 @@ def test_sample_reproducible_under_manual_seed(gpu_model):
     b = gpu_model._sample(eval_sp_size=2, num_steps=4)
     assert torch.equal(a, b)
     assert gpu_model._sample(eval_sp_size=0, num_steps=4).shape == (0, 200)
+
+
+def test_sample_long_sequence_vs_oracle(dev, det_sd):
+    """BASELINE.json configs[4] shape: L = 1024 (beyond the fused kernel's 224: the fp32 kernels run it), short schedule."""
+    from oracle import drakes_oracle as O
+    from oracle import philox
+    L, steps, B, seed = 1024, 6, 2, 77
+    m = drakes_amd.Diffusion(drakes_amd.default_config(length=L, steps=steps)).to(dev)
+    m.load_state_dict(det_sd)
+    toks = m._sample(eval_sp_size=B, seed=seed).cpu()
+    want = O.sample(det_sd, B, L, steps, lambda i, shp: torch.from_numpy(philox.step_uniforms(seed, i, shp[0], shp[1])))
+    assert toks.shape == (B, L) and torch.equal(toks, want)
+    m.hip_dtype = 'bf16'
+    with pytest.raises(NotImplementedError):
+        m._sample(eval_sp_size=B, seed=seed)

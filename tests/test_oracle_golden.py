@@ -114,3 +114,38 @@ def test_f5_finetune_gradient(det_sd):
             assert np.abs(got - ref).max() <= 1e-4 * scale, name
     gn = torch.sqrt(sum((v.grad.double() ** 2).sum() for v in sd.values() if v.grad is not None)).item()
     assert abs(gn - float(g['grad_norm'])) <= 1e-4 * float(g['grad_norm'])
+
+
+def test_f6_finetune_loop_oracle():
+    """oracle/finetune_oracle.py against what the reference's own fine_tune produced (fixture F6 b: one optimizer step,
+    truncated KL, soft copy flag)."""
+    from types import SimpleNamespace as NS
+    from oracle import finetune_oracle as FO
+    from drakes_amd.det_init import det_state_dict
+    g = load_golden('f6_finetune_loop_b.npz')
+    lr = float(g['lr'])
+    args = NS(truncate_steps=int(g['trunc']), gumbel_temp=float(g['temp']), total_num_steps=int(g['steps']), learning_rate=lr,
+              num_epochs=int(g['epochs']), num_accum_steps=int(g['accum']), batch_size=int(g['batch']),
+              copy_flag_temp=float(g['cft']), truncate_kl=bool(int(g['truncate_kl'])), alpha=float(g['alpha']),
+              alpha_schedule_warmup=int(g['warmup']), gradnorm_clip=1.0)
+    sd = det_state_dict(int(g['wseed']), 128, int(g['stacks']))
+    gen = np.random.Generator(np.random.PCG64(int(g['old_perturb_seed'])))
+    sd_old = {k: (v + 0.02 * torch.from_numpy(gen.standard_normal(tuple(v.shape)).astype(np.float32))
+                  if k != 'backbone.time_embedder.0.W' else v.clone()) for k, v in sd.items()}
+    sd_new = {k: v.clone().requires_grad_(k != 'backbone.time_embedder.0.W') for k, v in sd.items()}
+    pnames = [k for k in sd if k != 'backbone.time_embedder.0.W']
+    base = int(g['base_seed'])
+    first = {}
+    losses, log = FO.fine_tune(sd_new, sd_old, pnames, FO.SyntheticReward(3), FO.SyntheticReward(4), args, 200,
+                               lambda i: base + i, record_first_grads=first)
+    np.testing.assert_allclose(np.array([float(x) for x in losses], dtype=np.float32), g['losses'], rtol=1e-5)
+    for key in g.files:
+        if key.startswith('grad1_'):
+            name = key[len('grad1_'):]
+            ref = torch.from_numpy(g[key])
+            assert float((first[name][:ref.shape[0]] - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) + 1e-9, name
+        if key.startswith('delta_'):
+            name = key[len('delta_'):]
+            ref = torch.from_numpy(g[key])
+            got = (sd_new[name].detach() - sd[name])[:ref.shape[0]]
+            assert float((got - ref).abs().mean()) <= 1e-3 * lr, name

@@ -17,6 +17,37 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'
 import drakes_amd  # noqa: E402
 
 
+def loop(a):
+    from types import SimpleNamespace as NS
+    dev = torch.device('cuda:0')
+    torch.manual_seed(0)
+    cfg = drakes_amd.default_config(length=a.length, steps=a.steps, truncate_steps=a.trunc)
+    new_model, old_model = drakes_amd.Diffusion(cfg).to(dev), drakes_amd.Diffusion(cfg).to(dev)
+    old_model.load_state_dict(new_model.state_dict())
+    reward = torch.nn.Sequential(torch.nn.Conv1d(4, 8, 5, padding=2), torch.nn.Tanh(), torch.nn.AdaptiveAvgPool1d(1),
+                                 torch.nn.Flatten(), torch.nn.Linear(8, 3), torch.nn.Unflatten(1, (3, 1))).to(dev)
+    for p in reward.parameters():
+        p.requires_grad_(False)
+    args = NS(truncate_steps=a.trunc, gumbel_temp=1.0, total_num_steps=a.steps, learning_rate=1e-4, num_epochs=1,
+              num_accum_steps=1, batch_size=a.batch, copy_flag_temp=None, truncate_kl=False, alpha=0.001,
+              alpha_schedule_warmup=0, gradnorm_clip=1.0, save_every_n_epochs=10 ** 9)
+    ts = []
+    for r in range(a.reps + 1):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        drakes_amd.fine_tune(new_model, reward, reward, old_model, args, verbose=False)
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+        print(f'rep {r}: {ts[-1]:.3f} s per optimizer step', flush=True)
+    res = {'workload': f'fine_tune optimizer step: _sample_finetune_gradient (K={a.trunc}) + reward + KL over all {a.steps} '
+                       f'steps (new + frozen model) + backward + clip + Adam, batch {a.batch}, L={a.length}, fp32 kernels',
+           'seconds_per_step': sorted(ts[1:])[len(ts[1:]) // 2], 'peak_mem_GiB': torch.cuda.max_memory_allocated() / 2 ** 30}
+    print(json.dumps(res), flush=True)
+    if a.json:
+        with open(a.json, 'w') as f:
+            json.dump(res, f, indent=1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--batch', type=int, default=128)
@@ -25,7 +56,10 @@ def main():
     ap.add_argument('--length', type=int, default=200)
     ap.add_argument('--reps', type=int, default=3)
     ap.add_argument('--json', default=None)
+    ap.add_argument('--loop', action='store_true', help='time whole fine_tune optimizer steps (sampling + reward + KL over all steps + Adam)')
     a = ap.parse_args()
+    if a.loop:
+        return loop(a)
     dev = torch.device('cuda:0')
     torch.manual_seed(0)
     cfg = drakes_amd.default_config(length=a.length, steps=a.steps, truncate_steps=a.trunc)
