@@ -118,7 +118,7 @@ __global__ void __launch_bounds__(256) k_ln_fwd(const float* __restrict__ feat, 
 // channels 8g+4*half..+3) and one float4 of B (its output channel, same input channels), then
 // issues 4 MFMAs per row tile.  Operands come straight from global memory: h rows are re-used by
 // the 4 waves and the 9 taps through L1/L2, the 590 KB of weights stay L2-resident.
-template <int MT>
+template <int MT, bool PF>
 __global__ void __launch_bounds__(256) k_conv_f32(const float* __restrict__ h, const float* __restrict__ w_pk,
                                                   const float* __restrict__ bias, const float* resid, float* out,
                                                   unsigned char* __restrict__ relu_mask, long M, int L, int taps, int dil,
@@ -138,31 +138,77 @@ __global__ void __launch_bounds__(256) k_conv_f32(const float* __restrict__ h, c
     pos[mt] = (int)(rows[mt] % L);
   }
   const int center = taps / 2;
-  for (int t = 0; t < taps; ++t) {
-    const int off = (t - center) * dil;
-    const float* src[MT];
-    bool ok[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const int p = pos[mt] + off;
-      ok[mt] = rows[mt] < M && p >= 0 && p < L;
-      src[mt] = h + (rows[mt] + off) * DRK_C + 4 * half;
-    }
-    const float* wsrc = w_pk + (((long)t * 32 + half) * DRK_C + co) * 4;
-#pragma unroll 4
-    for (int g = 0; g < 16; ++g) {
-      const f32x4 b = *(const f32x4*)(wsrc + (long)g * (2 * DRK_C * 4));
-      f32x4 a[MT];
+  if (!PF) {
+    for (int t = 0; t < taps; ++t) {
+      const int off = (t - center) * dil;
+      const float* src[MT];
+      bool ok[MT];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
-        a[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (ok[mt]) a[mt] = *(const f32x4*)(src[mt] + 8 * g);
+        const int p = pos[mt] + off;
+        ok[mt] = rows[mt] < M && p >= 0 && p < L;
+        src[mt] = h + (rows[mt] + off) * DRK_C + 4 * half;
       }
+      const float* wsrc = w_pk + (((long)t * 32 + half) * DRK_C + co) * 4;
+#pragma unroll 4
+      for (int g = 0; g < 16; ++g) {
+        const f32x4 b = *(const f32x4*)(wsrc + (long)g * (2 * DRK_C * 4));
+        f32x4 a[MT];
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+        for (int mt = 0; mt < MT; ++mt) {
+          a[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (ok[mt]) a[mt] = *(const f32x4*)(src[mt] + 8 * g);
+        }
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-          acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][j], b[j], acc[mt], 0, 0, 0);
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][j], b[j], acc[mt], 0, 0, 0);
+      }
+    }
+  } else {
+    // K runs over (tap, 32-channel group): 4 groups per tap, each 4 x (8 channels = 4 MFMAs per row tile).  The operands
+    // of group i+1 are loaded BEFORE the MFMAs of group i (ping-pong registers): one wave then keeps the MFMA pipe
+    // busy through the L2 latency instead of idling between bursts, which is what small batches (one wave per SIMD) need.
+    struct Group {
+      f32x4 b[4];
+      f32x4 a[MT][4];
+    };
+    auto load_group = [&](int idx, Group& G) {
+      const int t = idx >> 2, gq = idx & 3;
+      const int off = (t - center) * dil;
+      const float* wsrc = w_pk + (((long)t * 32 + half) * DRK_C + co) * 4 + (long)(4 * gq) * (2 * DRK_C * 4);
+  #pragma unroll
+      for (int k = 0; k < 4; ++k) G.b[k] = *(const f32x4*)(wsrc + (long)k * (2 * DRK_C * 4));
+  #pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int p = pos[mt] + off;
+        const bool ok = rows[mt] < M && p >= 0 && p < L;
+        const float* src = h + (rows[mt] + off) * DRK_C + 4 * half + 32 * gq;
+  #pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          G.a[mt][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (ok) G.a[mt][k] = *(const f32x4*)(src + 8 * k);
+        }
+      }
+    };
+    auto mma_group = [&](const Group& G) {
+  #pragma unroll
+      for (int k = 0; k < 4; ++k)
+  #pragma unroll
+        for (int j = 0; j < 4; ++j)
+  #pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(G.a[mt][k][j], G.b[k][j], acc[mt], 0, 0, 0);
+    };
+    const int ngroups = 4 * taps;   // even
+    Group g0, g1;
+    load_group(0, g0);
+    for (int idx = 0; idx < ngroups; idx += 2) {
+      load_group(idx + 1, g1);
+      mma_group(g0);
+      if (idx + 2 < ngroups) load_group(idx + 2, g0);
+      mma_group(g1);
     }
   }
   const float bco = bias ? bias[co] : 0.0f;
@@ -272,8 +318,15 @@ extern "C" int drk_conv_fwd_f32(const float* h, const float* w_pk, const float* 
   ARGCHECK(h && w_pk && out && B >= 0 && L > 0 && taps >= 1 && (taps & 1) && dilation >= 0, "drk_conv_fwd_f32");
   const long M = (long)B * L;
   if (M == 0) return DRK_OK;
-  hipLaunchKernelGGL(k_conv_f32<2>, dim3((unsigned)((M + 63) / 64)), dim3(256), 0, (hipStream_t)stream, h, w_pk, bias,
-                     resid, out, relu_mask, M, L, taps, dilation, relu);
+  if (M >= 64L * 512)        // large batches: 64-row tiles (each weight fragment feeds 8 MFMAs)
+    hipLaunchKernelGGL((k_conv_f32<2, false>), dim3((unsigned)((M + 63) / 64)), dim3(256), 0, (hipStream_t)stream, h, w_pk,
+                       bias, resid, out, relu_mask, M, L, taps, dilation, relu);
+  else if (M > 32L * 384)    // 32-row tiles, twice the workgroups
+    hipLaunchKernelGGL((k_conv_f32<1, false>), dim3((unsigned)((M + 31) / 32)), dim3(256), 0, (hipStream_t)stream, h, w_pk,
+                       bias, resid, out, relu_mask, M, L, taps, dilation, relu);
+  else                       // at most ~1.5 workgroups per CU: software-prefetched operands
+    hipLaunchKernelGGL((k_conv_f32<1, true>), dim3((unsigned)((M + 31) / 32)), dim3(256), 0, (hipStream_t)stream, h, w_pk,
+                       bias, resid, out, relu_mask, M, L, taps, dilation, relu);
   DRK_CHECK_LAUNCH();
   return DRK_OK;
 }

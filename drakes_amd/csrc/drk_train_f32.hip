@@ -114,32 +114,59 @@ __global__ void __launch_bounds__(256) k_ln_bwd(const float* __restrict__ dh, co
 // GEMM with K = rows on the f32-input MFMA: A = h^T [32 ci x 2 rows], B = dc [2 rows x 32 co]; both operands are
 // row-contiguous, so every wave-load is two dense 128-byte spans.  Workgroup = (row chunk, tap); wave w = ci tile w,
 // all four co tiles.  Partial 128x128 tiles are added with fp32 atomics, 32 consecutive co per half-wave.
-#define WG_ROWS 512
+// Weight gradient of one tap: dW_t[ci][co] = sum_rows h[row + off][ci] * dc[row][co].  Grid = (row chunks, taps); a
+// workgroup reduces `wg_rows` rows with f32 MFMAs (K = 2 rows per instruction) and adds its 128x128 partial with fp32
+// atomics.  wg_rows is chosen by the host so that small batches still fill the chip.
 __global__ void __launch_bounds__(256) k_conv_wgrad(const float* __restrict__ h, const float* __restrict__ dc,
-                                                    float* __restrict__ dwt, long M, int L, int taps, int dil) {
+                                                    float* __restrict__ dwt, long M, int L, int taps, int dil, int wg_rows) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int half = lane >> 5, lr = lane & 31;
   const int t = blockIdx.y;
   const int off = (t - taps / 2) * dil;
-  const long r0 = (long)blockIdx.x * WG_ROWS;
+  const long r0 = (long)blockIdx.x * wg_rows;
   f32x16 acc[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
-  for (int s = 0; s < WG_ROWS / 2; ++s) {
-    const long row = r0 + 2 * s + half;
-    if (r0 + 2 * s >= M) break;
-    float a = 0.f;
-    f32x4 bq = {0.f, 0.f, 0.f, 0.f};
-    if (row < M) {
-      const int p = (int)(row % L) + off;
-      if (p >= 0 && p < L) a = h[(row + off) * DRK_C + 32 * w + lr];
-      const float* d = dc + row * DRK_C + lr;
-      bq = f32x4{d[0], d[32], d[64], d[96]};
+  const long rend = (r0 + wg_rows < M) ? r0 + wg_rows : M;
+  int p = (int)((r0 + half) % L);                      // position of this lane's first row; advanced by 2 per step
+  const float* hp = h + (r0 + half + off) * DRK_C + 32 * w + lr;
+  const float* dp = dc + (r0 + half) * DRK_C + lr;
+  const int nsteps = (int)((rend - r0 + 1) >> 1);     // both half-waves run the same trip count
+  // operands of step s+1 are loaded before the MFMAs of step s (the loop is load-latency-bound otherwise)
+  auto fetch = [&](int s, float& a, f32x4& bq) {
+    a = 0.f;
+    bq = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (s < nsteps && r0 + half + 2 * s < rend) {
+      const int q = p + off;
+      if (q >= 0 && q < L) a = *hp;
+      bq = f32x4{dp[0], dp[32], dp[64], dp[96]};
     }
+    hp += 2 * DRK_C;
+    dp += 2 * DRK_C;
+    p += 2;
+    if (p >= L) p -= L;
+    if (p >= L) p -= L;
+  };
+  float a0, a1, a2, a3;
+  f32x4 b0, b1, b2, b3;
+  fetch(0, a0, b0);
+  fetch(1, a1, b1);
+  fetch(2, a2, b2);
+  for (int s = 0; s < nsteps; s += 4) {   // 3 steps of loads in flight
+    fetch(s + 3, a3, b3);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq[j], acc[j], 0, 0, 0);
+    for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0[j], acc[j], 0, 0, 0);
+    fetch(s + 4, a0, b0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1[j], acc[j], 0, 0, 0);
+    fetch(s + 5, a1, b1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2[j], acc[j], 0, 0, 0);
+    fetch(s + 6, a2, b2);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, b3[j], acc[j], 0, 0, 0);
   }
   float* dst = dwt + (long)t * DRK_C * DRK_C;
 #pragma unroll
@@ -557,8 +584,11 @@ extern "C" int drk_conv_wgrad_f32(const float* h, const float* dc, float* dwt, i
   DRK_SHAPE_GUARD("drk_conv_wgrad_f32");
   ARGCHECK(h && dc && dwt && taps >= 1 && (taps & 1) && dilation >= 0, "drk_conv_wgrad_f32");
   const long M = (long)B * L;
-  hipLaunchKernelGGL(k_conv_wgrad, dim3((unsigned)((M + WG_ROWS - 1) / WG_ROWS), (unsigned)taps), dim3(256), 0,
-                     (hipStream_t)stream, h, dc, dwt, M, L, taps, dilation);
+  // >= ~2 workgroups per CU when the batch allows it; fewer rows per workgroup cost more atomics (64 KB each)
+  int wg_rows = 512;
+  while (wg_rows > 64 && ((M + wg_rows - 1) / wg_rows) * taps < 512) wg_rows >>= 1;
+  hipLaunchKernelGGL(k_conv_wgrad, dim3((unsigned)((M + wg_rows - 1) / wg_rows), (unsigned)taps), dim3(256), 0,
+                     (hipStream_t)stream, h, dc, dwt, M, L, taps, dilation, wg_rows);
   DRK_CHECK_LAUNCH();
   return DRK_OK;
 }
