@@ -108,6 +108,45 @@ __global__ void __launch_bounds__(256) k_denoise_argmax(const float* __restrict_
   }
 }
 
+// Forward noising q(x_t | x_0) of the absorbing process (diffusion_gosai_update.py:425-436): a position becomes the
+// mask token with probability move_chance.  ONE uniform per position (the reference draws torch.rand(*x.shape)): the
+// first of the step's Philox uniforms, or uniforms[i] when injected.
+template <bool INJECT>
+__global__ void __launch_bounds__(256) k_q_xt(const int64_t* __restrict__ x0, const float* __restrict__ uniforms,
+                                              int64_t* __restrict__ xt, long n, int L, float move_chance, uint64_t seed,
+                                              uint32_t step, uint64_t sample_offset) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float u;
+    if (INJECT) {
+      u = uniforms[i];
+    } else {
+      float uu[DRK_V];
+      const uint32_t row = (uint32_t)i / (uint32_t)L;
+      drk_step_uniforms(seed, step, sample_offset + row, (uint32_t)i - row * (uint32_t)L, uu);
+      u = uu[0];
+    }
+    xt[i] = (u < move_chance) ? (int64_t)DRK_MASK : x0[i];
+  }
+}
+
+// One term of get_likelihood (diffusion_gosai_update.py:911-917): acc[b,l] += multiplier * log p(x0[b,l] | x_t), with
+// the SUBS log-probability taken from raw logits (0 where x_t still shows the token).
+__global__ void __launch_bounds__(256) k_likelihood_accum(const float* __restrict__ logits, const int64_t* __restrict__ x0,
+                                                          const int64_t* __restrict__ xt, float multiplier,
+                                                          float* __restrict__ acc, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float lg[DRK_V], lp[DRK_V];
+    load5(logits, i, lg);
+    drk_subs_logp(lg, (int)xt[i], lp);
+    const int tok = (int)x0[i];
+    float v = lp[0];
+#pragma unroll
+    for (int k = 1; k < DRK_V; ++k)
+      if (tok == k) v = lp[k];
+    acc[i] += v * multiplier;
+  }
+}
+
 // ------------------------------------------------------------------------------------ C ABI
 static inline int grid_for(long n) {
   long g = (n + 255) / 256;
@@ -167,6 +206,33 @@ extern "C" int drk_denoise_argmax(const float* logits, const int64_t* x, int64_t
   const long n = (long)B * L;
   if (n == 0) return DRK_OK;
   hipLaunchKernelGGL(k_denoise_argmax, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, logits, x, x_out, n);
+  DRK_CHECK_LAUNCH();
+  return DRK_OK;
+}
+
+extern "C" int drk_q_xt(const int64_t* x0, const float* uniforms, int64_t* xt, int B, int L, float move_chance,
+                        uint64_t seed, uint32_t step, uint64_t sample_offset, void* stream) {
+  DRK_SHAPE_GUARD("drk_q_xt");
+  if (!x0 || !xt) return drk_set_error_msg(DRK_EINVAL, "drk_q_xt: bad arguments");
+  const long n = (long)B * L;
+  if (n >= (1L << 32)) return drk_set_error_msg(DRK_EINVAL, "drk_q_xt: B*L must be below 2^32");
+  if (uniforms)
+    hipLaunchKernelGGL(k_q_xt<true>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x0, uniforms, xt, n, L,
+                       move_chance, seed, step, sample_offset);
+  else
+    hipLaunchKernelGGL(k_q_xt<false>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x0, uniforms, xt, n, L,
+                       move_chance, seed, step, sample_offset);
+  DRK_CHECK_LAUNCH();
+  return DRK_OK;
+}
+
+extern "C" int drk_likelihood_accum(const float* logits, const int64_t* x0, const int64_t* xt, float multiplier,
+                                    float* acc, int B, int L, void* stream) {
+  DRK_SHAPE_GUARD("drk_likelihood_accum");
+  if (!logits || !x0 || !xt || !acc) return drk_set_error_msg(DRK_EINVAL, "drk_likelihood_accum: bad arguments");
+  const long n = (long)B * L;
+  hipLaunchKernelGGL(k_likelihood_accum, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, logits, x0, xt, multiplier,
+                     acc, n);
   DRK_CHECK_LAUNCH();
   return DRK_OK;
 }

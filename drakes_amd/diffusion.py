@@ -160,6 +160,53 @@ class Diffusion(nn.Module):
             x = ops.denoise_argmax(logits, x)
         return x
 
+    # ------------------------------------------------------------------ likelihood
+    def q_xt(self, x, move_chance, *, seed=None, step=0, sample_offset=0, uniforms=None):
+        """Computes the noisy sample xt — reference :425-436.  move_chance: [B,1], all rows equal (as get_likelihood
+        builds it) or a float."""
+        mc = move_chance
+        if torch.is_tensor(mc):
+            if not bool((mc == mc.reshape(-1)[0]).all()):
+                raise NotImplementedError('per-row move_chance: the kernel takes one value per call')
+            mc = float(mc.reshape(-1)[0])
+        if seed is None and uniforms is None:
+            seed = self._draw_seed()
+        return ops.q_xt(x.contiguous(), mc, seed or 0, step, sample_offset, uniforms)
+
+    @torch.no_grad()
+    def get_likelihood(self, x0, num_steps=None, eps=1e-5, n_samples=1, *, seed=None, sample_offset=0, uniforms=None):
+        """Compute the likelihood of a sequence under the model — reference :885-926.
+
+        x0: int64 [B, L] on the device.  uniforms: optional callable (sample, step) -> float32 [B,L] replacing the
+        in-kernel Philox draw (sample s uses seed + s)."""
+        if num_steps is None:
+            num_steps = self.config.sampling.steps
+        if seed is None:
+            seed = self._draw_seed()
+        x0 = x0.contiguous()
+        B, L = x0.shape
+        table, _, _, _ = noise_schedule.step_table(self.noise, num_steps, eps)
+        table = table.tolist()
+        bb = self.backbone
+        shared = None if self.time_conditioning else self._shared_time_bias(0.0)
+        total = torch.zeros(B, dtype=torch.float32, device=x0.device)
+        acc = torch.empty(B, L, dtype=torch.float32, device=x0.device)
+        xt = torch.empty_like(x0)
+        for s in range(n_samples):
+            acc.zero_()
+            for i in range(num_steps):
+                _, sigma_t, mc_t, mc_s = table[i]
+                # (move_chance_t - move_chance_s) / move_chance_t in fp32, as the reference computes it (:908)
+                mult = float((torch.tensor(mc_t, dtype=torch.float32) - torch.tensor(mc_s, dtype=torch.float32))
+                             / torch.tensor(mc_t, dtype=torch.float32))
+                u = uniforms(s, i) if uniforms is not None else None
+                ops.q_xt(x0, mc_t, seed + s, i, sample_offset, u, out=xt)
+                tb = shared if shared is not None else self._shared_time_bias(sigma_t)
+                logits = bb.forward_f32(xt, tb, 0, self._work)
+                ops.likelihood_accum(logits, x0, xt, mult, acc)
+            total += acc.sum(dim=-1)
+        return total / n_samples
+
     # ------------------------------------------------------------------ fine-tuning sampler
     def _ddpm_update_finetune_gradient(self, x, t, dt, copy_flag_temp, return_process=False, **kw):
         from . import finetune

@@ -305,3 +305,19 @@ def kl_step_bwd(logp, logp_old, last_x, flag, grad_kl, mc_t, want_dold, want_dx,
               _f(grad_kl, 'grad_kl'), float(mc_t), _f(dlogp, 'dlogp'), _f(dold, 'dlogp_old'), _f(dx, 'dlast_x'),
               _f(dflag, 'dflag'), B, L, _stream())
     return dlogp, dold, dx, dflag
+
+
+# ---- likelihood ----------------------------------------------------------------------------------
+def q_xt(x0, move_chance, seed=0, step=0, sample_offset=0, uniforms=None, out=None):
+    B, L = x0.shape
+    xt = out if out is not None else torch.empty_like(x0)
+    _lib.call('drk_q_xt', _i(x0, 'x0'), _f(uniforms, 'uniforms'), _i(xt, 'xt'), B, L, float(move_chance), seed, step,
+              sample_offset, _stream())
+    return xt
+
+
+def likelihood_accum(logits, x0, xt, multiplier, acc):
+    B, L = x0.shape
+    _lib.call('drk_likelihood_accum', _f(logits, 'logits'), _i(x0, 'x0'), _i(xt, 'xt'), float(multiplier), _f(acc, 'acc'),
+              B, L, _stream())
+    return acc

@@ -62,6 +62,17 @@ int drk_reverse_step_hard(const float* logits, const int64_t* x, const float* un
 /* Noise-removal: SUBS, then argmax over the 4 nucleotides — _sample, :541-549. */
 int drk_denoise_argmax(const float* logits, const int64_t* x, int64_t* x_out, int B, int L, void* stream);
 
+/* ---- likelihood -------------------------------------------------------------- */
+/* q(x_t | x_0): Diffusion.q_xt, diffusion_gosai_update.py:425-436.  x0, xt int64 [B][L]; a position is masked when its
+ * uniform < move_chance.  uniforms: float32 [B][L] (ONE per position, as torch.rand(*x.shape) there) or NULL = the
+ * first Philox uniform of (seed, step, sample_offset + row, position). */
+int drk_q_xt(const int64_t* x0, const float* uniforms, int64_t* xt, int B, int L, float move_chance, uint64_t seed,
+             uint32_t step, uint64_t sample_offset, void* stream);
+/* One time step of Diffusion.get_likelihood, diffusion_gosai_update.py:911-917: acc[b][l] += multiplier *
+ * log p(x0[b][l] | x_t) from RAW backbone logits [B][L][5] (SUBS applied inside).  acc float32 [B][L]. */
+int drk_likelihood_accum(const float* logits, const int64_t* x0, const int64_t* xt, float multiplier, float* acc,
+                         int B, int L, void* stream);
+
 /* ---- denoiser (CNNModel.forward, models/dnaconv.py:74-110), fp32 ---------------------------- */
 /* relu(Linear(GaussianFourierProjection(sigma))) — dnaconv.py:19-21,50,82.
  * sigma [nb]; W [64]; lin_w [128][128]; lin_b [128]; temb [nb][128]. */

@@ -260,3 +260,30 @@ def kl_step(logp_new, logp_old, last_x, copy_flag, mc_t_scalar):
     p, po = lp.exp(), lo.exp()
     kl = copy_flag * (-p + po + p * (lp - lo)) / mc_t_scalar
     return (kl * last_x[:, :, :-1]).sum((1, 2))
+
+
+# --------------------------------------------------------------------------- likelihood
+def q_xt(x, move_chance, u):
+    """Diffusion.q_xt with the uniform draw injected — diffusion_gosai_update.py:425-436.  u: [B,L] in [0,1)."""
+    return torch.where(u < move_chance, MASK_INDEX, x)
+
+
+def get_likelihood(sd, x0, num_steps, uniform_fn, eps=1e-5, n_samples=1, time_conditioning=False):
+    """Diffusion.get_likelihood — diffusion_gosai_update.py:885-926.  uniform_fn(sample, step) -> float32 [B,L]."""
+    with torch.no_grad():
+        timesteps, dt = timestep_grid(num_steps, eps)
+        per_sample = []
+        for s in range(n_samples):
+            at_time = []
+            for i in range(num_steps):
+                t = timesteps[i] * torch.ones(x0.shape[0], 1)
+                sigma_t = total_noise(t).squeeze(-1)
+                sigma_s = total_noise(t - dt).squeeze(-1)
+                mc_t = (1 - torch.exp(-sigma_t))[:, None]
+                mc_s = (1 - torch.exp(-sigma_s))[:, None]
+                multiplier = (mc_t - mc_s) / mc_t
+                xt = q_xt(x0, mc_t, uniform_fn(s, i))
+                out = model_forward(sd, xt, sigma_t, time_conditioning)
+                at_time.append(out.gather(-1, x0[..., None]).squeeze(-1) * multiplier)
+            per_sample.append(torch.stack(at_time, dim=0).sum(dim=0).sum(dim=-1))
+        return torch.stack(per_sample, dim=0).mean(dim=0)

@@ -149,3 +149,15 @@ def test_f6_finetune_loop_oracle():
             ref = torch.from_numpy(g[key])
             got = (sd_new[name].detach() - sd[name])[:ref.shape[0]]
             assert float((got - ref).abs().mean()) <= 1e-3 * lr, name
+
+
+def test_f7_likelihood_oracle(det_sd):
+    g = load_golden('f7_likelihood.npz')
+    x0 = torch.from_numpy(g['x0'])
+    B, L = x0.shape
+    seed = int(g['useed'])
+    u = lambda s, i: torch.from_numpy(philox.step_uniforms(seed + s, i, B, L)[:, :, 0].copy())
+    ll = O.get_likelihood(det_sd, x0, int(g['steps_tc']), u, n_samples=int(g['n_samples']), time_conditioning=True)
+    np.testing.assert_allclose(ll.numpy(), g['loglik_tc'], rtol=1e-6)
+    assert torch.equal(O.q_xt(x0, float(g['qxt_mc']), torch.from_numpy(philox.step_uniforms(seed, int(g['qxt_step']), B, L)[:, :, 0].copy())),
+                       torch.from_numpy(g['qxt']))
