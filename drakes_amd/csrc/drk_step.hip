@@ -147,6 +147,36 @@ __global__ void __launch_bounds__(256) k_likelihood_accum(const float* __restric
   }
 }
 
+// Graph-replayable form of the hard step: everything that changes from step to step comes from device memory, so ONE
+// captured launch sequence (hipGraph) serves every step and every call.  params[k] = (mc_t, mc_s) of step k; rng =
+// (seed, sample_offset); *counter = the current
+// step, advanced by k_step_advance (a separate 1-thread node AFTER the step kernel: no block of the step kernel can
+// observe the increment).
+__global__ void __launch_bounds__(256)
+    k_reverse_step_hard_table(const float* __restrict__ logits, const int64_t* x, int64_t* x_next, long n, int L,
+                              const float* __restrict__ params, const int* __restrict__ counter,
+                              const uint64_t* __restrict__ rng) {
+  const int step = *counter;
+  const uint64_t seed = rng[0], sample_offset = rng[1];
+  const float mc_t = params[2 * step], mc_s = params[2 * step + 1];
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int tok = (int)x[i];
+    int out = tok;
+    if (tok == DRK_MASK) {
+      float lg[DRK_V], lp[DRK_V], q[DRK_V], u[DRK_V];
+      load5(logits, i, lg);
+      const uint32_t row = (uint32_t)i / (uint32_t)L;
+      drk_step_uniforms(seed, (uint32_t)step, sample_offset + row, (uint32_t)i - row * (uint32_t)L, u);
+      drk_subs_logp(lg, DRK_MASK, lp);
+      drk_posterior(lp, mc_t, mc_s, q);
+      out = drk_gumbel_argmax(q, u);
+    }
+    x_next[i] = out;
+  }
+}
+
+__global__ void k_step_advance(int* counter) { *counter += 1; }
+
 // ------------------------------------------------------------------------------------ C ABI
 static inline int grid_for(long n) {
   long g = (n + 255) / 256;
@@ -233,6 +263,22 @@ extern "C" int drk_likelihood_accum(const float* logits, const int64_t* x0, cons
   const long n = (long)B * L;
   hipLaunchKernelGGL(k_likelihood_accum, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, logits, x0, xt, multiplier,
                      acc, n);
+  DRK_CHECK_LAUNCH();
+  return DRK_OK;
+}
+
+extern "C" int drk_reverse_step_hard_table(const float* logits, const int64_t* x, int64_t* x_next, int B, int L,
+                                           const float* mc_table, int* step_counter, const uint64_t* rng,
+                                           void* stream) {
+  DRK_SHAPE_GUARD("drk_reverse_step_hard_table");
+  if (!logits || !x || !x_next || !mc_table || !step_counter || !rng)
+    return drk_set_error_msg(DRK_EINVAL, "drk_reverse_step_hard_table: bad arguments");
+  const long n = (long)B * L;
+  if (n >= (1L << 32)) return drk_set_error_msg(DRK_EINVAL, "drk_reverse_step_hard_table: B*L must be below 2^32");
+  hipLaunchKernelGGL(k_reverse_step_hard_table, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, logits, x, x_next, n,
+                     L, mc_table, step_counter, rng);
+  DRK_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_step_advance, dim3(1), dim3(1), 0, (hipStream_t)stream, step_counter);
   DRK_CHECK_LAUNCH();
   return DRK_OK;
 }

@@ -12,7 +12,8 @@ Differences a caller can see, all additive:
     defaults to a draw from torch's CPU generator, so `torch.manual_seed(s)` still makes a run
     reproducible.  `uniforms=` injects explicit noise (tests), `sample_offset=` is the global
     index of row 0 (data-parallel shards draw the noise of their own rows).
-  * `hip_dtype` ('fp32' | 'bf16') selects the exact-fp32 kernels or the bf16-MFMA fast path.
+  * `hip_dtype` ('fp32' | 'bf16') selects the exact-fp32 kernels or the bf16-MFMA fast path (one launch per
+    `_sample`); `hip_graph = True` replays the fp32 step loop from a captured hipGraph.
 """
 import torch
 import torch.nn as nn
@@ -44,6 +45,8 @@ class Diffusion(nn.Module):
         self.time_conditioning = self.config.time_conditioning
         self.neg_infinity = -1000000.0
         self.hip_dtype = 'fp32'
+        self.hip_graph = False          # fp32 path: replay the step loop from a captured hipGraph (see _sample_graph)
+        self._graph = None
         self._validate_configuration()
         self._work = {}
 
@@ -148,6 +151,9 @@ class Diffusion(nn.Module):
             return fastpath.sample_bf16(self, x, table, float(sigma_last), seed, sample_offset, uniforms)
         bb = self.backbone
         shared = None if self.time_conditioning else self._shared_time_bias(0.0)
+        if self.hip_graph and uniforms is None and shared is not None and num_steps > 0:
+            x = self._sample_graph(x, table, shared, seed, sample_offset)
+            num_steps = 0                      # the loop below is skipped; noise removal follows
         for i in range(num_steps):
             _, sigma_t, mc_t, mc_s = table[i]
             tb = shared if shared is not None else self._shared_time_bias(sigma_t)
@@ -159,6 +165,43 @@ class Diffusion(nn.Module):
             logits = bb.forward_f32(x, tb, 0, self._work)
             x = ops.denoise_argmax(logits, x)
         return x
+
+    def _sample_graph(self, x, table, shared, seed, sample_offset):
+        """The step loop of _sample as ONE captured launch sequence (hipGraph), replayed once per step: the launches of
+        a step (denoiser forward + fused reverse step) are recorded once per (batch, length); what changes from step to
+        step or call to call (move chances, the Philox step index, seed) is read from device memory by the step kernel.  Removes the
+        per-launch host cost (147 launches per step) at small batches.  Not with time conditioning or injected noise."""
+        B, L = x.shape
+        num_steps = len(table)
+        dev = x.device
+        mc = torch.tensor([[row[2], row[3]] for row in table], dtype=torch.float32, device=dev)
+        key = (B, L, num_steps, shared.data_ptr(), self.backbone._weights_key())
+        st = self._graph
+        if st is None or st['key'] != key:
+            st = {'key': key, 'x': torch.empty_like(x), 'counter': torch.zeros(1, dtype=torch.int32, device=dev), 'mc': mc,
+                  'rng': torch.zeros(2, dtype=torch.int64, device=dev)}
+            st['x'].copy_(x)
+            work = {}
+            self.backbone.packed()
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):          # warm-up outside capture: allocates the work buffers
+                logits = self.backbone.forward_f32(st['x'], shared, 0, work)
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                logits = self.backbone.forward_f32(st['x'], shared, 0, work)
+                ops.reverse_step_hard_table(logits, st['x'], st['mc'], st['counter'], st['rng'], out=st['x'])
+            st['graph'], st['work'] = graph, work
+            self._graph = st
+        st['x'].copy_(x)
+        st['mc'].copy_(mc)
+        st['counter'].zero_()
+        as_i64 = lambda v: v - (1 << 64) if v >= (1 << 63) else v          # uint64 bit pattern in an int64 tensor
+        st['rng'].copy_(torch.tensor([as_i64(seed), as_i64(sample_offset)], dtype=torch.int64))
+        for _ in range(num_steps):
+            st['graph'].replay()
+        return st['x'].clone()
 
     # ------------------------------------------------------------------ likelihood
     def q_xt(self, x, move_chance, *, seed=None, step=0, sample_offset=0, uniforms=None):

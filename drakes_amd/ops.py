@@ -321,3 +321,13 @@ def likelihood_accum(logits, x0, xt, multiplier, acc):
     _lib.call('drk_likelihood_accum', _f(logits, 'logits'), _i(x0, 'x0'), _i(xt, 'xt'), float(multiplier), _f(acc, 'acc'),
               B, L, _stream())
     return acc
+
+
+def reverse_step_hard_table(logits, x, mc_table, step_counter, rng, out):
+    """Graph-replayable hard step: per-step scalars, the step index and (seed, sample_offset) come from device memory."""
+    B, L = x.shape
+    if step_counter.dtype != torch.int32 or rng.dtype != torch.int64 or rng.numel() != 2:
+        raise TypeError('step_counter: int32 [1]; rng: int64 [2] (the bit patterns of two uint64)')
+    _lib.call('drk_reverse_step_hard_table', _f(logits, 'logits'), _i(x, 'x'), _i(out, 'x_next'), B, L,
+              _f(mc_table, 'mc_table'), ctypes.c_void_p(step_counter.data_ptr()), _i(rng, 'rng'), _stream())
+    return out

@@ -62,6 +62,14 @@ int drk_reverse_step_hard(const float* logits, const int64_t* x, const float* un
 /* Noise-removal: SUBS, then argmax over the 4 nucleotides — _sample, :541-549. */
 int drk_denoise_argmax(const float* logits, const int64_t* x, int64_t* x_out, int B, int L, void* stream);
 
+/* The same step in a form a captured launch sequence (hipGraph) can replay for every step: (mc_t, mc_s) of step k are
+ * mc_table[2k], mc_table[2k+1] (device, float32 [num_steps][2]) and the step index is *step_counter (device int),
+ * which this call advances by one after the step (a separate one-thread launch); rng = device uint64 [2] =
+ * (seed, sample_offset).  In-kernel Philox noise only.
+ * Same arithmetic as drk_reverse_step_hard (diffusion_gosai_update.py:462-486 + the loop of :524-539). */
+int drk_reverse_step_hard_table(const float* logits, const int64_t* x, int64_t* x_next, int B, int L,
+                                const float* mc_table, int* step_counter, const uint64_t* rng, void* stream);
+
 /* ---- likelihood -------------------------------------------------------------- */
 /* q(x_t | x_0): Diffusion.q_xt, diffusion_gosai_update.py:425-436.  x0, xt int64 [B][L]; a position is masked when its
  * uniform < move_chance.  uniforms: float32 [B][L] (ONE per position, as torch.rand(*x.shape) there) or NULL = the

@@ -82,3 +82,18 @@ def test_sample_long_sequence_vs_oracle(dev, det_sd):
     m.hip_dtype = 'bf16'
     with pytest.raises(NotImplementedError):
         m._sample(eval_sp_size=B, seed=seed)
+
+
+def test_sample_hip_graph_matches_plain_loop(gpu_model):
+    """hip_graph = True replays the captured step (forward + fused reverse step): same tokens, any seed, reused graph."""
+    try:
+        for seed, off in ((5, 0), (6, 3), (2 ** 63 + 11, 1)):
+            gpu_model.hip_graph = False
+            want = gpu_model._sample(eval_sp_size=6, seed=seed, sample_offset=off)
+            gpu_model.hip_graph = True
+            got = gpu_model._sample(eval_sp_size=6, seed=seed, sample_offset=off)
+            assert torch.equal(got, want)
+        assert gpu_model._graph is not None
+    finally:
+        gpu_model.hip_graph = False
+        gpu_model._graph = None
