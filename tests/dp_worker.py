@@ -59,6 +59,7 @@ def main():
     ap.add_argument('--stacks', type=int, default=1)
     ap.add_argument('--seed', type=int, default=1234)
     ap.add_argument('--hip-dtype', default='fp32')
+    ap.add_argument('--finetune', action='store_true', help='also run one drakes_amd.fine_tune optimizer step (gpu mode)')
     a = ap.parse_args()
     faulthandler.dump_traceback_later(150, exit=True)      # a stuck collective names itself instead of hanging
 
@@ -95,7 +96,25 @@ def main():
     norm = bucket.clip_grad_norm_(1.0)
     views_ok = all(p.grad.data_ptr() == bucket.flat.data_ptr() + 4 * off for p, off in zip(bucket.params, bucket.offsets))
 
-    torch.save({'tokens': tokens.cpu(), 'first': first, 'mine': mine.cpu(), 'mine_first': mine_first,
+    ft = {}
+    if a.finetune and a.mode == 'gpu':
+        from types import SimpleNamespace as NS
+        from oracle.finetune_oracle import SyntheticReward
+        model.hip_dtype = 'fp32'
+        start = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        old_model = drakes_amd.Diffusion(cfg).to(device)
+        old_model.load_state_dict(det_state_dict(8, 128, a.stacks))
+        fargs = NS(truncate_steps=a.trunc, gumbel_temp=1.0, total_num_steps=a.steps, learning_rate=1e-4, num_epochs=1,
+                   num_accum_steps=2, batch_size=a.grad_batch // world, copy_flag_temp=None, truncate_kl=False, alpha=0.01,
+                   alpha_schedule_warmup=0, gradnorm_clip=1.0, save_every_n_epochs=10 ** 9)
+        reward = SyntheticReward(3).to(device)
+        losses = drakes_amd.fine_tune(model, reward, reward, old_model, fargs, seed_of_call=lambda i: 500 + i, verbose=False)
+        ft = {'ft_losses': torch.tensor([float(x) for x in losses]),
+              'ft_delta': torch.cat([(model.state_dict()[k] - start[k]).flatten().cpu()
+                                     for k in ('backbone.final_conv.2.weight', 'backbone.norms.3.weight', 'backbone.linear.weight')]),
+              'ft_norm': drakes_amd.fine_tune.last_log['tot_grad_norm']}
+
+    torch.save({**ft, 'tokens': tokens.cpu(), 'first': first, 'mine': mine.cpu(), 'mine_first': mine_first,
                 'flat': bucket.flat.cpu(), 'local_flat': local_flat.cpu(), 'norm': float(norm),
                 'views_ok': views_ok, 'loss': float(loss)},
                os.path.join(a.out, f'rank{rank}.pt'))

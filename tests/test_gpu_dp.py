@@ -25,3 +25,20 @@ def test_world2_matches_world1_on_gpu(tmp_path, hip_dtype):
     scale = float(one['flat'].abs().max())
     assert float((two[0]['flat'] - one['flat']).abs().max()) <= 1e-4 * scale
     assert abs(two[0]['norm'] - one['norm']) <= 1e-4 * one['norm']
+
+
+@pytest.mark.timeout(600)
+def test_fine_tune_world2_matches_world1(tmp_path):
+    """drakes_amd.fine_tune under data parallelism: two ranks with 2 rows each take the optimizer step one process takes
+    with 4 rows (same global rows, same noise; the bucket is all-reduced once, after the last micro-step, then clipped)."""
+    extra = ['--global-batch', 4, '--grad-batch', 4, '--length', 200, '--steps', 10, '--trunc', 3, '--stacks', 4, '--finetune']
+    one = run_world(1, 'gpu', str(tmp_path / 'w1'), extra)[0]
+    two = run_world(2, 'gpu', str(tmp_path / 'w2'), extra)
+    lr = 1e-4
+    assert torch.equal(two[0]['ft_delta'], two[1]['ft_delta'])               # both ranks took the same step
+    d = (two[0]['ft_delta'] - one['ft_delta']).abs()
+    print('mean |d|/lr', float(d.mean()) / lr, 'fraction beyond 0.1 lr', float((d > 0.1 * lr).float().mean()))
+    assert float(d.mean()) <= 0.01 * lr and float((d > 0.1 * lr).float().mean()) <= 0.01
+    assert abs(two[0]['ft_norm'] - one['ft_norm']) <= 1e-3 * one['ft_norm']
+    mean_two = 0.5 * (two[0]['ft_losses'] + two[1]['ft_losses'])
+    assert torch.allclose(mean_two, one['ft_losses'], rtol=1e-4, atol=1e-5)
