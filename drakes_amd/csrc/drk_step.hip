@@ -177,6 +177,79 @@ __global__ void __launch_bounds__(256)
 
 __global__ void k_step_advance(int* counter) { *counter += 1; }
 
+// ---- wide vocabulary (protein inverse folding, V = 22): Interpolant.sample, drakes_protein/fmif/fm_utils.py:113-134 ----
+// Same absorbing-diffusion step with a sampling temperature: logp = logits/temp - logsumexp(logits/temp) with the mask
+// logit at -1e6, q = exp(logp) * d_t, q[mask] = move_chance_s, Gumbel-argmax, carry-over; plus the clean prediction
+// argmax over the non-mask logits.  One lane per position; its V logits are V*4 contiguous bytes.
+#define DRK_VMAX 32
+__device__ __forceinline__ void drk_step_uniforms_wide(uint64_t seed, uint32_t step, uint64_t sample, uint32_t pos,
+                                                       int nclass, float* u) {
+  const float sc = 5.9604644775390625e-08f;  // 2^-24
+  for (int blk = 0; 4 * blk < nclass; ++blk) {
+    uint32_t r[4];
+    drk_philox4x32_10(pos, (uint32_t)sample, step, 0x50524F54u ^ (uint32_t)(sample >> 32) ^ ((uint32_t)blk << 24),
+                      (uint32_t)seed, (uint32_t)(seed >> 32), r);
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+      if (4 * blk + w < nclass) u[4 * blk + w] = (float)(r[w] >> 8) * sc;
+  }
+}
+
+template <int V, bool INJECT>
+__global__ void __launch_bounds__(256)
+    k_reverse_step_hard_wide(const float* __restrict__ logits, const int64_t* x, const float* __restrict__ uniforms,
+                             int64_t* x_next, int64_t* __restrict__ pred_clean, long n, int L, int mask_index, float temp,
+                             float d_t, float mc_s, uint64_t seed, uint32_t step, uint64_t sample_offset) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float lg[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) lg[v] = logits[i * V + v];
+    if (pred_clean) {   // argmax over the logits with the mask column at -1e9 (first index wins, :115-117)
+      int best = 0;
+      float bv = (0 == mask_index) ? -1e9f : lg[0];
+#pragma unroll
+      for (int v = 1; v < V; ++v) {
+        const float c = (v == mask_index) ? -1e9f : lg[v];
+        if (c > bv) { bv = c; best = v; }
+      }
+      pred_clean[i] = best;
+    }
+    const int tok = (int)x[i];
+    int out = tok;
+    if (tok == mask_index) {
+      float m = -INFINITY;
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        lg[v] = ((v == mask_index) ? DRK_NEG_INF : lg[v]) / temp;
+        m = fmaxf(m, lg[v]);
+      }
+      const float ms = (fabsf(m) == INFINITY) ? 0.0f : m;
+      float s = 0.0f;
+#pragma unroll
+      for (int v = 0; v < V; ++v) s += expf(lg[v] - ms);
+      const float lse = logf(s) + ms;
+      float u[V];
+      if (INJECT) {
+#pragma unroll
+        for (int v = 0; v < V; ++v) u[v] = uniforms[i * V + v];
+      } else {
+        const uint32_t row = (uint32_t)i / (uint32_t)L;
+        drk_step_uniforms_wide(seed, step, sample_offset + row, (uint32_t)i - row * (uint32_t)L, V, u);
+      }
+      float bv = 0.0f;
+      int best = 0;
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        const float q = (v == mask_index) ? mc_s : expf(lg[v] - lse) * d_t;
+        const float r = q / (1e-10f - logf(u[v] + 1e-10f));
+        if (v == 0 || r > bv) { bv = r; best = v; }
+      }
+      out = best;
+    }
+    x_next[i] = out;
+  }
+}
+
 // ------------------------------------------------------------------------------------ C ABI
 static inline int grid_for(long n) {
   long g = (n + 255) / 256;
@@ -279,6 +352,26 @@ extern "C" int drk_reverse_step_hard_table(const float* logits, const int64_t* x
                      L, mc_table, step_counter, rng);
   DRK_CHECK_LAUNCH();
   hipLaunchKernelGGL(k_step_advance, dim3(1), dim3(1), 0, (hipStream_t)stream, step_counter);
+  DRK_CHECK_LAUNCH();
+  return DRK_OK;
+}
+
+extern "C" int drk_reverse_step_hard_wide(const float* logits, const int64_t* x, const float* uniforms, int64_t* x_next,
+                                          int64_t* pred_clean, int B, int L, int V, int mask_index, float temp, float d_t,
+                                          float move_chance_s, uint64_t seed, uint32_t step, uint64_t sample_offset,
+                                          void* stream) {
+  DRK_SHAPE_GUARD("drk_reverse_step_hard_wide");
+  if (!logits || !x || !x_next || temp <= 0.f || mask_index < 0 || mask_index >= V)
+    return drk_set_error_msg(DRK_EINVAL, "drk_reverse_step_hard_wide: bad arguments");
+  if (V != 22) return drk_set_error_msg(DRK_EINVAL, "drk_reverse_step_hard_wide: built for V = 22 (20 amino acids, X, mask)");
+  const long n = (long)B * L;
+  if (n >= (1L << 32)) return drk_set_error_msg(DRK_EINVAL, "drk_reverse_step_hard_wide: B*L must be below 2^32");
+  if (uniforms)
+    hipLaunchKernelGGL((k_reverse_step_hard_wide<22, true>), dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, logits, x,
+                       uniforms, x_next, pred_clean, n, L, mask_index, temp, d_t, move_chance_s, seed, step, sample_offset);
+  else
+    hipLaunchKernelGGL((k_reverse_step_hard_wide<22, false>), dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, logits, x,
+                       uniforms, x_next, pred_clean, n, L, mask_index, temp, d_t, move_chance_s, seed, step, sample_offset);
   DRK_CHECK_LAUNCH();
   return DRK_OK;
 }

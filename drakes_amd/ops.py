@@ -331,3 +331,16 @@ def reverse_step_hard_table(logits, x, mc_table, step_counter, rng, out):
     _lib.call('drk_reverse_step_hard_table', _f(logits, 'logits'), _i(x, 'x'), _i(out, 'x_next'), B, L,
               _f(mc_table, 'mc_table'), ctypes.c_void_p(step_counter.data_ptr()), _i(rng, 'rng'), _stream())
     return out
+
+
+# ---- wide vocabulary (protein, V = 22) -------------------------------------------------------------
+def reverse_step_hard_wide(logits, x, d_t, move_chance_s, temp=1.0, mask_index=21, seed=0, step=0, sample_offset=0,
+                           uniforms=None, out=None, want_clean=True):
+    """One step of the protein sampler (fm_utils.py:113-134).  Returns (x_next, pred_clean or None)."""
+    B, L, Vw = logits.shape
+    x_next = out if out is not None else torch.empty_like(x)
+    clean = torch.empty_like(x) if want_clean else None
+    _lib.call('drk_reverse_step_hard_wide', _f(logits, 'logits'), _i(x, 'x'), _f(uniforms, 'uniforms'), _i(x_next, 'x_next'),
+              _i(clean, 'pred_clean'), B, L, Vw, mask_index, float(temp), float(d_t), float(move_chance_s), seed, step,
+              sample_offset, _stream())
+    return x_next, clean

@@ -70,6 +70,17 @@ int drk_denoise_argmax(const float* logits, const int64_t* x, int64_t* x_out, in
 int drk_reverse_step_hard_table(const float* logits, const int64_t* x, int64_t* x_next, int B, int L,
                                 const float* mc_table, int* step_counter, const uint64_t* rng, void* stream);
 
+/* ---- wide vocabulary: the protein reverse step ------------------------------------- */
+/* One step of Interpolant.sample, drakes_protein/fmif/fm_utils.py:113-134, from the model's logits float32 [B][L][V]
+ * (V = 22: 20 amino acids, X, mask = index 21): temperature, mask logit at -1e6, log-softmax, held tokens kept,
+ * q = exp(logp)*d_t with q[mask] = move_chance_s, Gumbel-argmax (_sample_categorical, :14-18), carry-over.
+ * x, x_next int64 [B][L] (may alias); pred_clean (optional) int64 [B][L] = argmax of the non-mask logits (:115-117).
+ * uniforms: float32 [B][L][V] or NULL = Philox blocks (position, sample, step, 0x50524F54 ^ sample_hi ^ block<<24),
+ * class c = word c%4 of block c/4. */
+int drk_reverse_step_hard_wide(const float* logits, const int64_t* x, const float* uniforms, int64_t* x_next,
+                               int64_t* pred_clean, int B, int L, int V, int mask_index, float temp, float d_t,
+                               float move_chance_s, uint64_t seed, uint32_t step, uint64_t sample_offset, void* stream);
+
 /* ---- likelihood -------------------------------------------------------------- */
 /* q(x_t | x_0): Diffusion.q_xt, diffusion_gosai_update.py:425-436.  x0, xt int64 [B][L]; a position is masked when its
  * uniform < move_chance.  uniforms: float32 [B][L] (ONE per position, as torch.rand(*x.shape) there) or NULL = the

@@ -287,3 +287,23 @@ def get_likelihood(sd, x0, num_steps, uniform_fn, eps=1e-5, n_samples=1, time_co
                 at_time.append(out.gather(-1, x0[..., None]).squeeze(-1) * multiplier)
             per_sample.append(torch.stack(at_time, dim=0).sum(dim=0).sum(dim=-1))
         return torch.stack(per_sample, dim=0).mean(dim=0)
+
+
+# --------------------------------------------------------------------------- wide vocabulary (protein, V = 22)
+def hard_step_wide(logits, x, u, d_t, move_chance_s, temp=1.0, mask_index=21, neg_infinity=-1000000.0):
+    """One reverse step of Interpolant.sample — /root/reference/drakes_protein/fmif/fm_utils.py:113-134 — from the
+    model's logits [B,L,V]: returns (x_next int64 [B,L], pred_clean int64 [B,L]).  u: injected uniforms [B,L,V]."""
+    pred_wo_mask = logits.clone()
+    pred_wo_mask[:, :, mask_index] = -1e9
+    pred_clean = torch.argmax(pred_wo_mask, dim=-1)
+    lg = logits.clone()
+    lg[:, :, mask_index] = neg_infinity
+    lg = lg / temp - torch.logsumexp(lg / temp, dim=-1, keepdim=True)
+    unmasked = (x != mask_index)
+    lg[unmasked] = neg_infinity
+    lg[unmasked, x[unmasked]] = 0
+    q = lg.exp() * d_t
+    q[:, :, mask_index] = move_chance_s
+    xs = (q / gumbel_norm(u)).argmax(dim=-1)
+    copy_flag = unmasked.to(x.dtype)
+    return (x * copy_flag + xs * (1 - copy_flag)).long(), pred_clean

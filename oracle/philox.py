@@ -83,3 +83,26 @@ KAT = [
     ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
      (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1)),
 ]
+
+
+WIDE_TAG = 0x50524F54   # 'PROT': domain tag of the wide-vocabulary stream (block index in the top byte)
+
+
+def step_uniforms_wide(seed, step, batch, length, nclass, sample_offset=0):
+    """float32 [batch, length, nclass] uniforms for one reverse step of a vocabulary wider than 5 (protein, V = 22):
+    class c takes word c % 4 of Philox block c // 4, counter = (position, sample lo, step,
+    WIDE_TAG ^ sample hi ^ (block << 24)), key = seed, U = (word >> 8) * 2^-24."""
+    seed = int(seed)
+    samp = np.arange(batch, dtype=np.uint64)[:, None] + np.uint64(sample_offset)
+    pos = np.arange(length, dtype=np.uint64)[None, :]
+    c1 = samp & _MASK32
+    u = np.empty((batch, length, nclass), dtype=np.float32)
+    scale = np.float32(2.0 ** -24)
+    for blk in range((nclass + 3) // 4):
+        c3 = np.uint64(WIDE_TAG) ^ (samp >> np.uint64(32)) ^ np.uint64(blk << 24)
+        r = philox4x32_10(pos, c1, np.uint64(step), c3, seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+        for w in range(4):
+            c = 4 * blk + w
+            if c < nclass:
+                u[..., c] = (r[w] >> np.uint32(8)).astype(np.float32) * scale
+    return u

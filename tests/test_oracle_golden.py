@@ -161,3 +161,17 @@ def test_f7_likelihood_oracle(det_sd):
     np.testing.assert_allclose(ll.numpy(), g['loglik_tc'], rtol=1e-6)
     assert torch.equal(O.q_xt(x0, float(g['qxt_mc']), torch.from_numpy(philox.step_uniforms(seed, int(g['qxt_step']), B, L)[:, :, 0].copy())),
                        torch.from_numpy(g['qxt']))
+
+
+def test_f8_protein_step_oracle():
+    g = load_golden('f8_protein_sample.npz')
+    table, traj, clean = torch.from_numpy(g['table']), torch.from_numpy(g['traj']), torch.from_numpy(g['clean'])
+    T = int(g['T'])
+    ts = torch.linspace(float(g['min_t']), 1.0, T)
+    x, t_1 = traj[0], ts[0]
+    B, L, V = table.shape[1:]
+    for k, t_2 in enumerate(ts[1:]):
+        u = torch.from_numpy(philox.step_uniforms_wide(int(g['useed']), k, B, L, V))
+        x, pc = O.hard_step_wide(table[k], x, u, t_2 - t_1, 1.0 - t_2, temp=float(g['temp']))
+        assert torch.equal(x, traj[k + 1]) and torch.equal(pc, clean[k])
+        t_1 = t_2
