@@ -75,11 +75,16 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', 1))
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
+    local_rank = local_rank % max(torch.cuda.device_count(), 1)   # only differs in the one-GPU rehearsal
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
+    backend = os.environ.get('DRK_BENCH_BACKEND', 'nccl')   # 'gloo': rehearsal of the N>1 path on a one-GPU box
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)        # RCCL over xGMI
+        else:
+            dist.init_process_group(backend)
 
     torch.manual_seed(0)
     model = drakes_amd.Diffusion(drakes_amd.default_config(length=L, steps=NUM_STEPS)).to(dev).eval()
@@ -108,7 +113,7 @@ def main():
     elapsed = time.perf_counter() - t0
     prof = ops.PROFILE.disable()
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=dev if backend == 'nccl' else 'cpu', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
     assert toks.shape == (B, L) and int(toks.max()) <= 3
