@@ -22,6 +22,10 @@ SIGNATURES = {
     'drk_reverse_step_hard_table': [_P, _P, _P, c_int, c_int, _P, _P, _P, _P],
     'drk_reverse_step_hard_wide': [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_uint64,
                                    c_uint32, c_uint64, _P],
+    'drk_reverse_step_soft_wide_fwd': [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_float,
+                                       c_uint64, c_uint32, c_uint64, _P],
+    'drk_reverse_step_soft_wide_bwd': [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, c_float,
+                                       c_float, c_uint64, c_uint32, c_uint64, _P],
     'drk_denoise_argmax': [_P, _P, _P, c_int, c_int, _P],
     'drk_q_xt': [_P, _P, _P, c_int, c_int, c_float, c_uint64, c_uint32, c_uint64, _P],
     'drk_likelihood_accum': [_P, _P, _P, c_float, _P, c_int, c_int, _P],

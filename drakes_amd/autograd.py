@@ -198,3 +198,29 @@ class _KLStepFn(torch.autograd.Function):
 
 def kl_step_with_grad(logp, logp_old, last_x, flag, mc_t):
     return _KLStepFn.apply(logp, logp_old, last_x, flag, float(mc_t))
+
+
+class _SoftStepWideFn(torch.autograd.Function):
+    """(x_next, flag) of the protein sampler's Gumbel-softmax step (fm_utils.py:159-192); noise recomputed in backward."""
+
+    @staticmethod
+    def forward(ctx, logits, x_soft, d_t, mc_s, temp, gtemp, mask_index, seed, step, sample_offset, uniforms):
+        logits, x_soft = logits.contiguous(), x_soft.contiguous()
+        x_next, flag = ops.reverse_step_soft_wide_fwd(logits, x_soft, d_t, mc_s, temp, gtemp, mask_index, seed, step,
+                                                      sample_offset, uniforms)
+        ctx.save_for_backward(logits, x_soft)
+        ctx.consts = (d_t, mc_s, temp, gtemp, mask_index, seed, step, sample_offset, uniforms)
+        return x_next, flag.unsqueeze(-1)
+
+    @staticmethod
+    def backward(ctx, g_next, g_flag):
+        logits, x_soft = ctx.saved_tensors
+        d_t, mc_s, temp, gtemp, mask_index, seed, step, sample_offset, uniforms = ctx.consts
+        gf = g_flag.reshape(g_flag.shape[0], g_flag.shape[1]).contiguous() if g_flag is not None else None
+        dlogits, dx = ops.reverse_step_soft_wide_bwd(logits, x_soft, g_next.contiguous(), gf, d_t, mc_s, temp, gtemp,
+                                                     mask_index, seed, step, sample_offset, uniforms)
+        return (dlogits, dx) + (None,) * 9
+
+
+def soft_step_wide_with_grad(logits, x_soft, d_t, mc_s, temp, gtemp, mask_index, seed, step, sample_offset, uniforms):
+    return _SoftStepWideFn.apply(logits, x_soft, d_t, mc_s, temp, gtemp, mask_index, seed, step, sample_offset, uniforms)

@@ -538,6 +538,136 @@ __global__ void __launch_bounds__(256) k_kl_bwd(const float* __restrict__ lp, co
   }
 }
 
+// ---- wide vocabulary (protein, V = 22): the Gumbel-softmax step of Interpolant.sample_gradient ----------------
+// drakes_protein/fmif/fm_utils.py:159-192 (soft branch) + _sample_categorical_gradient (:21-26):
+//   l = logits / temp with the mask logit at -1e6;  lp = l - logsumexp(l), or (-1e6 .. 0 at argmax x .. -1e6) when
+//   argmax x is not the mask;  q = exp(lp) * d_t, q[mask] = move_chance_s, q += 1e-8;  g = 1e-10 - log(U + 1e-10);
+//   y = softmax((log q - log g) / gumbel_temp);  flag = 1 - x[mask];  x_next = x * flag + y * (1 - flag)
+template <int V>
+__device__ __forceinline__ void wide_uniforms(uint64_t seed, uint32_t step, uint64_t sample, uint32_t pos, float (&u)[V]) {
+  const float sc = 5.9604644775390625e-08f;
+#pragma unroll
+  for (int blk = 0; 4 * blk < V; ++blk) {
+    uint32_t r[4];
+    drk_philox4x32_10(pos, (uint32_t)sample, step, 0x50524F54u ^ (uint32_t)(sample >> 32) ^ ((uint32_t)blk << 24),
+                      (uint32_t)seed, (uint32_t)(seed >> 32), r);
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+      if (4 * blk + w < V) u[4 * blk + w] = (float)(r[w] >> 8) * sc;
+  }
+}
+
+template <int V>
+__device__ __forceinline__ void soft_row_wide(const float (&lg)[V], const float (&xs)[V], const float (&u)[V], int mask,
+                                              float temp, float d_t, float mc_s, float inv_gtemp, int& tok, float (&lp)[V],
+                                              float (&q)[V], float (&y)[V], float& flag) {
+  tok = 0;
+#pragma unroll
+  for (int k = 1; k < V; ++k)
+    if (xs[k] > xs[tok]) tok = k;
+  float l[V], m = -INFINITY;
+#pragma unroll
+  for (int v = 0; v < V; ++v) {
+    l[v] = ((v == mask) ? DRK_NEG_INF : lg[v]) / temp;
+    m = fmaxf(m, l[v]);
+  }
+  const float ms = (fabsf(m) == INFINITY) ? 0.0f : m;
+  float s = 0.f;
+#pragma unroll
+  for (int v = 0; v < V; ++v) s += expf(l[v] - ms);
+  const float lse = logf(s) + ms;
+  float z[V], zm = -INFINITY;
+#pragma unroll
+  for (int v = 0; v < V; ++v) {
+    lp[v] = (tok != mask) ? ((v == tok) ? 0.0f : DRK_NEG_INF) : l[v] - lse;
+    q[v] = ((v == mask) ? mc_s : expf(lp[v]) * d_t) + 1e-8f;
+    const float g = 1e-10f - logf(u[v] + 1e-10f);
+    z[v] = (logf(q[v]) - logf(g)) * inv_gtemp;
+    zm = fmaxf(zm, z[v]);
+  }
+  float ys = 0.f;
+#pragma unroll
+  for (int v = 0; v < V; ++v) {
+    y[v] = expf(z[v] - zm);
+    ys += y[v];
+  }
+#pragma unroll
+  for (int v = 0; v < V; ++v) y[v] = y[v] / ys;
+  flag = 1.0f - xs[mask];
+}
+
+template <int V, bool INJECT>
+__global__ void __launch_bounds__(128)
+    k_soft_step_wide_fwd(const float* __restrict__ logits, const float* __restrict__ x_soft, const float* __restrict__ uniforms,
+                         float* __restrict__ x_next, float* __restrict__ flag_out, long n, int L, int mask, float temp,
+                         float d_t, float mc_s, float inv_gtemp, uint64_t seed, uint32_t step, uint64_t sample_offset) {
+  for (long i = (long)blockIdx.x * 128 + threadIdx.x; i < n; i += (long)gridDim.x * 128) {
+    float lg[V], xs[V], u[V], lp[V], q[V], y[V], flag;
+    int tok;
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      lg[v] = logits[i * V + v];
+      xs[v] = x_soft[i * V + v];
+    }
+    if (INJECT) {
+#pragma unroll
+      for (int v = 0; v < V; ++v) u[v] = uniforms[i * V + v];
+    } else {
+      const uint32_t row = (uint32_t)i / (uint32_t)L;
+      wide_uniforms<V>(seed, step, sample_offset + row, (uint32_t)i - row * (uint32_t)L, u);
+    }
+    soft_row_wide<V>(lg, xs, u, mask, temp, d_t, mc_s, inv_gtemp, tok, lp, q, y, flag);
+#pragma unroll
+    for (int v = 0; v < V; ++v) x_next[i * V + v] = xs[v] * flag + y[v] * (1.0f - flag);
+    flag_out[i] = flag;
+  }
+}
+
+template <int V, bool INJECT>
+__global__ void __launch_bounds__(128)
+    k_soft_step_wide_bwd(const float* __restrict__ logits, const float* __restrict__ x_soft, const float* __restrict__ uniforms,
+                         const float* __restrict__ gnext, const float* __restrict__ gflag, float* __restrict__ dlogits,
+                         float* __restrict__ dx, long n, int L, int mask, float temp, float d_t, float mc_s, float inv_gtemp,
+                         uint64_t seed, uint32_t step, uint64_t sample_offset) {
+  for (long i = (long)blockIdx.x * 128 + threadIdx.x; i < n; i += (long)gridDim.x * 128) {
+    float lg[V], xs[V], u[V], lp[V], q[V], y[V], G[V], flag;
+    int tok;
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      lg[v] = logits[i * V + v];
+      xs[v] = x_soft[i * V + v];
+      G[v] = gnext[i * V + v];
+    }
+    if (INJECT) {
+#pragma unroll
+      for (int v = 0; v < V; ++v) u[v] = uniforms[i * V + v];
+    } else {
+      const uint32_t row = (uint32_t)i / (uint32_t)L;
+      wide_uniforms<V>(seed, step, sample_offset + row, (uint32_t)i - row * (uint32_t)L, u);
+    }
+    soft_row_wide<V>(lg, xs, u, mask, temp, d_t, mc_s, inv_gtemp, tok, lp, q, y, flag);
+    float dflag = gflag ? gflag[i] : 0.f, dyy = 0.f;
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      dflag += G[v] * (xs[v] - y[v]);
+      dyy += y[v] * ((1.0f - flag) * G[v]);
+    }
+    float dlp[V], sdl = 0.f;
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      const float dz = y[v] * ((1.0f - flag) * G[v] - dyy);
+      const float e = expf(lp[v]) * d_t;                    // q = e + 1e-8: d log q / d lp = e / q
+      dlp[v] = (v == mask || tok != mask) ? 0.f : dz * inv_gtemp * (e / q[v]);
+      sdl += dlp[v];
+    }
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      dlogits[i * V + v] = (v == mask || tok != mask) ? 0.f : (dlp[v] - expf(lp[v]) * sdl) / temp;
+      dx[i * V + v] = flag * G[v] - ((v == mask) ? dflag : 0.f);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------ C ABI
 extern "C" int drk_mask_mul(const float* g, const unsigned char* mask, float* out, long n, void* stream) {
   ARGCHECK(n >= 0 && (n % 4) == 0, "drk_mask_mul");
@@ -698,6 +828,49 @@ extern "C" int drk_kl_step_bwd(const float* logp, const float* logp_old, const f
   const long n = (long)B * L;
   hipLaunchKernelGGL(k_kl_bwd, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, logp, logp_old, last_x, flag_f,
                      flag_i, grad_kl, 1.0f / move_chance_t, dlogp, dlogp_old, dlast_x, dflag, n, L);
+  DRK_CHECK_LAUNCH();
+  return DRK_OK;
+}
+
+extern "C" int drk_reverse_step_soft_wide_fwd(const float* logits, const float* x_soft, const float* uniforms, float* x_next,
+                                              float* flag, int B, int L, int V, int mask_index, float temp, float d_t,
+                                              float move_chance_s, float gumbel_temp, uint64_t seed, uint32_t step,
+                                              uint64_t sample_offset, void* stream) {
+  DRK_SHAPE_GUARD("drk_reverse_step_soft_wide_fwd");
+  ARGCHECK(logits && x_soft && x_next && flag && temp > 0.f && gumbel_temp > 0.f && V == 22 && mask_index >= 0 &&
+               mask_index < V, "drk_reverse_step_soft_wide_fwd (V must be 22)");
+  const long n = (long)B * L;
+  ARGCHECK(n < (1L << 32), "drk_reverse_step_soft_wide_fwd (B*L must be below 2^32)");
+  if (uniforms)
+    hipLaunchKernelGGL((k_soft_step_wide_fwd<22, true>), dim3(grid_for(n, 128)), dim3(128), 0, (hipStream_t)stream, logits,
+                       x_soft, uniforms, x_next, flag, n, L, mask_index, temp, d_t, move_chance_s, 1.0f / gumbel_temp, seed,
+                       step, sample_offset);
+  else
+    hipLaunchKernelGGL((k_soft_step_wide_fwd<22, false>), dim3(grid_for(n, 128)), dim3(128), 0, (hipStream_t)stream, logits,
+                       x_soft, uniforms, x_next, flag, n, L, mask_index, temp, d_t, move_chance_s, 1.0f / gumbel_temp, seed,
+                       step, sample_offset);
+  DRK_CHECK_LAUNCH();
+  return DRK_OK;
+}
+
+extern "C" int drk_reverse_step_soft_wide_bwd(const float* logits, const float* x_soft, const float* uniforms,
+                                              const float* grad_x_next, const float* grad_flag, float* dlogits, float* dx,
+                                              int B, int L, int V, int mask_index, float temp, float d_t, float move_chance_s,
+                                              float gumbel_temp, uint64_t seed, uint32_t step, uint64_t sample_offset,
+                                              void* stream) {
+  DRK_SHAPE_GUARD("drk_reverse_step_soft_wide_bwd");
+  ARGCHECK(logits && x_soft && grad_x_next && dlogits && dx && temp > 0.f && gumbel_temp > 0.f && V == 22 &&
+               mask_index >= 0 && mask_index < V, "drk_reverse_step_soft_wide_bwd (V must be 22)");
+  const long n = (long)B * L;
+  ARGCHECK(n < (1L << 32), "drk_reverse_step_soft_wide_bwd (B*L must be below 2^32)");
+  if (uniforms)
+    hipLaunchKernelGGL((k_soft_step_wide_bwd<22, true>), dim3(grid_for(n, 128)), dim3(128), 0, (hipStream_t)stream, logits,
+                       x_soft, uniforms, grad_x_next, grad_flag, dlogits, dx, n, L, mask_index, temp, d_t, move_chance_s,
+                       1.0f / gumbel_temp, seed, step, sample_offset);
+  else
+    hipLaunchKernelGGL((k_soft_step_wide_bwd<22, false>), dim3(grid_for(n, 128)), dim3(128), 0, (hipStream_t)stream, logits,
+                       x_soft, uniforms, grad_x_next, grad_flag, dlogits, dx, n, L, mask_index, temp, d_t, move_chance_s,
+                       1.0f / gumbel_temp, seed, step, sample_offset);
   DRK_CHECK_LAUNCH();
   return DRK_OK;
 }

@@ -344,3 +344,25 @@ def reverse_step_hard_wide(logits, x, d_t, move_chance_s, temp=1.0, mask_index=2
               _i(clean, 'pred_clean'), B, L, Vw, mask_index, float(temp), float(d_t), float(move_chance_s), seed, step,
               sample_offset, _stream())
     return x_next, clean
+
+
+def reverse_step_soft_wide_fwd(logits, x_soft, d_t, move_chance_s, temp, gumbel_temp, mask_index=21, seed=0, step=0,
+                               sample_offset=0, uniforms=None):
+    B, L, Vw = x_soft.shape
+    x_next = torch.empty_like(x_soft)
+    flag = torch.empty(B, L, dtype=torch.float32, device=x_soft.device)
+    _lib.call('drk_reverse_step_soft_wide_fwd', _f(logits, 'logits'), _f(x_soft, 'x_soft'), _f(uniforms, 'uniforms'),
+              _f(x_next, 'x_next'), _f(flag, 'flag'), B, L, Vw, mask_index, float(temp), float(d_t), float(move_chance_s),
+              float(gumbel_temp), seed, step, sample_offset, _stream())
+    return x_next, flag
+
+
+def reverse_step_soft_wide_bwd(logits, x_soft, grad_x_next, grad_flag, d_t, move_chance_s, temp, gumbel_temp, mask_index=21,
+                               seed=0, step=0, sample_offset=0, uniforms=None):
+    B, L, Vw = x_soft.shape
+    dlogits, dx = torch.empty_like(logits), torch.empty_like(x_soft)
+    _lib.call('drk_reverse_step_soft_wide_bwd', _f(logits, 'logits'), _f(x_soft, 'x_soft'), _f(uniforms, 'uniforms'),
+              _f(grad_x_next, 'grad_x_next'), _f(grad_flag, 'grad_flag'), _f(dlogits, 'dlogits'), _f(dx, 'dx'), B, L, Vw,
+              mask_index, float(temp), float(d_t), float(move_chance_s), float(gumbel_temp), seed, step, sample_offset,
+              _stream())
+    return dlogits, dx

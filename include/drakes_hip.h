@@ -81,6 +81,20 @@ int drk_reverse_step_hard_wide(const float* logits, const int64_t* x, const floa
                                int64_t* pred_clean, int B, int L, int V, int mask_index, float temp, float d_t,
                                float move_chance_s, uint64_t seed, uint32_t step, uint64_t sample_offset, void* stream);
 
+/* The Gumbel-softmax step of Interpolant.sample_gradient, drakes_protein/fmif/fm_utils.py:159-192 (soft branch) with
+ * _sample_categorical_gradient (:21-26): x_soft, x_next float32 [B][L][V]; flag float32 [B][L] = 1 - x_soft[mask].
+ * q gets the reference's +1e-8 floor (:181).  V = 22. */
+int drk_reverse_step_soft_wide_fwd(const float* logits, const float* x_soft, const float* uniforms, float* x_next,
+                                   float* flag, int B, int L, int V, int mask_index, float temp, float d_t,
+                                   float move_chance_s, float gumbel_temp, uint64_t seed, uint32_t step,
+                                   uint64_t sample_offset, void* stream);
+/* Its backward: given grad_x_next [B][L][V] (and optionally grad_flag [B][L]), writes dlogits and the direct dx; the
+ * forward row is recomputed from (logits, x_soft, noise). */
+int drk_reverse_step_soft_wide_bwd(const float* logits, const float* x_soft, const float* uniforms,
+                                   const float* grad_x_next, const float* grad_flag, float* dlogits, float* dx, int B,
+                                   int L, int V, int mask_index, float temp, float d_t, float move_chance_s,
+                                   float gumbel_temp, uint64_t seed, uint32_t step, uint64_t sample_offset, void* stream);
+
 /* ---- likelihood -------------------------------------------------------------- */
 /* q(x_t | x_0): Diffusion.q_xt, diffusion_gosai_update.py:425-436.  x0, xt int64 [B][L]; a position is masked when its
  * uniform < move_chance.  uniforms: float32 [B][L] (ONE per position, as torch.rand(*x.shape) there) or NULL = the

@@ -307,3 +307,48 @@ def hard_step_wide(logits, x, u, d_t, move_chance_s, temp=1.0, mask_index=21, ne
     xs = (q / gumbel_norm(u)).argmax(dim=-1)
     copy_flag = unmasked.to(x.dtype)
     return (x * copy_flag + xs * (1 - copy_flag)).long(), pred_clean
+
+
+def sample_gradient_wide(model_fn, batch, length, num_timesteps, min_t, temp, truncate_steps, gumbel_temp, uniform_fn,
+                         num_tokens=22, mask_index=21, neg_infinity=-1000000.0):
+    """Interpolant.sample_gradient — /root/reference/drakes_protein/fmif/fm_utils.py:142-209.  model_fn(k, x_soft) ->
+    logits [B,L,V] (stands for ProteinMPNN); uniform_fn(k) -> [B,L,V].  Returns the reference's 4-tuple."""
+    x1 = F.one_hot(torch.full((batch, length), mask_index), num_classes=num_tokens).float()
+    ts = torch.linspace(min_t, 1.0, num_timesteps)
+    t_1 = ts[0]
+    last_x_list, mct_list, flag_list = [], [], []
+    for k, t_2 in enumerate(ts[1:]):
+        d_t = t_2 - t_1
+        lg = model_fn(k, x1).clone()
+        lg[:, :, mask_index] = neg_infinity
+        lg = lg / temp - torch.logsumexp(lg / temp, dim=-1, keepdim=True)
+        am = x1.argmax(dim=-1)
+        unmasked = (am != mask_index)
+        held = torch.full_like(lg, neg_infinity).scatter(-1, am.unsqueeze(-1), 0.0)
+        lg = torch.where(unmasked.unsqueeze(-1), held, lg)
+        move_chance_t = 1.0 - t_1
+        move_chance_s = 1.0 - t_2
+        q = lg.exp() * d_t
+        col = torch.zeros(num_tokens, dtype=torch.bool)
+        col[mask_index] = True
+        q = torch.where(col, move_chance_s.expand_as(q[..., :1]), q)
+        u = uniform_fn(k)
+        if k < num_timesteps - truncate_steps:
+            xs = F.one_hot((q / gumbel_norm(u)).argmax(dim=-1), num_classes=num_tokens).float()
+            flag = unmasked.to(x1.dtype).unsqueeze(-1)
+            x2 = (x1 * flag + xs * (1 - flag)).detach()
+            x1 = x1.detach()
+        else:
+            q = q + 1e-8
+            xs = F.softmax((torch.log(q) - torch.log(gumbel_norm(u))) / gumbel_temp, 2)
+            flag = 1 - x1[:, :, mask_index].unsqueeze(-1)
+            x2 = x1 * flag + xs * (1 - flag)
+        last_x_list.append(x1)
+        mct_list.append(move_chance_t + min_t)
+        flag_list.append(flag)
+        x1, t_1 = x2, t_2
+    last_x_list.append(x1)
+    mct_list.append(1.0 - t_1 + min_t)
+    flag_list.append(1 - x1[:, :, mask_index].unsqueeze(-1))
+    hard = F.one_hot(x1[:, :, :-1].argmax(dim=-1), num_classes=num_tokens).float()
+    return x1 + (hard - x1).detach(), last_x_list, mct_list, flag_list

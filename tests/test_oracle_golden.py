@@ -175,3 +175,16 @@ def test_f8_protein_step_oracle():
         x, pc = O.hard_step_wide(table[k], x, u, t_2 - t_1, 1.0 - t_2, temp=float(g['temp']))
         assert torch.equal(x, traj[k + 1]) and torch.equal(pc, clean[k])
         t_1 = t_2
+
+
+def test_f9_protein_sample_gradient_oracle():
+    g = load_golden('f9_protein_sample_gradient.npz')
+    tab = torch.from_numpy(g['table']).requires_grad_()
+    mix, W = torch.from_numpy(g['mix']), torch.from_numpy(g['W'])
+    B, L, V = tab.shape[1:]
+    out, lx, mct, cf = O.sample_gradient_wide(lambda k, xs: tab[k] + xs @ mix, B, L, int(g['T']), float(g['min_t']),
+                                              float(g['temp']), int(g['K']), float(g['gumbel_temp']),
+                                              lambda k: torch.from_numpy(philox.step_uniforms_wide(int(g['useed']), k, B, L, V)))
+    (out * W).sum().backward()
+    np.testing.assert_allclose(out.detach().numpy(), g['sample'], rtol=1e-6, atol=1e-7)
+    assert float((tab.grad - torch.from_numpy(g['grad_table'])).abs().max()) <= 1e-5 * float(np.abs(g['grad_table']).max())
