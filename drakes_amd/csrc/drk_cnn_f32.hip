@@ -228,6 +228,92 @@ __global__ void __launch_bounds__(256) k_conv_f32(const float* __restrict__ h, c
   }
 }
 
+// ------------------------------------------------------------------------------------ conv, large batches
+// Same implicit GEMM, 64 rows x 128 output channels per workgroup, but the activation tile of each tap goes through
+// LDS.  In k_conv_f32 a lane's A fragment is 16 bytes of ITS row, so one wave-load touches 64 different 128-byte
+// lines and the texture path, not the MFMA, paces the kernel (59 % of the f32 MFMA peak).  Here the 64 x 512-byte rows
+// of a tap are fetched as whole rows (fully coalesced, 8 x 16 B per thread), parked in LDS with 528-byte rows
+// (conflict-free ds_read_b128 for the fragment pattern), and the NEXT tap's rows are in flight in registers while the
+// current tap's 128 MFMAs per wave run.  Weights still stream from L2 (coalesced, 590 KB per layer).
+#define CL_ROWS 64
+#define CL_STRIDE 132   // floats per LDS row (128 + 4 pad)
+__global__ void __launch_bounds__(256) k_conv_f32_lds(const float* __restrict__ h, const float* __restrict__ w_pk,
+                                                      const float* __restrict__ bias, const float* resid, float* out,
+                                                      unsigned char* __restrict__ relu_mask, long M, int L, int taps, int dil,
+                                                      int relu) {
+  __shared__ __attribute__((aligned(16))) float tile[2][CL_ROWS * CL_STRIDE];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int half = lane >> 5, lr = lane & 31;
+  const long r0 = (long)blockIdx.x * CL_ROWS;
+  const int co = 32 * w + lr;
+  f32x16 acc[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[mt][i] = 0.0f;
+  // staging role of this thread: rows srow + 8 i (i < 8), 16-byte chunk scol of each
+  const int srow = tid >> 5, scol = tid & 31;
+  int spos[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) spos[i] = (int)((r0 + srow + 8 * i) % L);
+  const int center = taps / 2;
+  f32x4 stage[8];
+  auto fetch = [&](int t) {
+    const int off = (t - center) * dil;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const long row = r0 + srow + 8 * i;
+      const int p = spos[i] + off;
+      stage[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (row < M && p >= 0 && p < L) stage[i] = *(const f32x4*)(h + (row + off) * DRK_C + 4 * scol);
+    }
+  };
+  auto park = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) *(f32x4*)(&tile[buf][(srow + 8 * i) * CL_STRIDE + 4 * scol]) = stage[i];
+  };
+  fetch(0);
+  park(0);
+  __syncthreads();
+  for (int t = 0; t < taps; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < taps) fetch(t + 1);               // in flight under this tap's MFMAs
+    const float* wsrc = w_pk + (((long)t * 32 + half) * DRK_C + co) * 4;
+    const float* a0 = &tile[buf][lr * CL_STRIDE + 4 * half];
+    const float* a1 = a0 + 32 * CL_STRIDE;
+#pragma unroll 4
+    for (int g = 0; g < 16; ++g) {
+      const f32x4 b = *(const f32x4*)(wsrc + (long)g * (2 * DRK_C * 4));
+      const f32x4 x0 = *(const f32x4*)(a0 + 8 * g);
+      const f32x4 x1 = *(const f32x4*)(a1 + 8 * g);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0[j], b[j], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[j], b[j], acc[1], 0, 0, 0);
+      }
+    }
+    if (t + 1 < taps) {
+      park(buf ^ 1);                              // the other buffer: its last readers finished before the previous barrier
+      __syncthreads();
+    }
+  }
+  const float bco = bias ? bias[co] : 0.0f;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const long row = r0 + 32 * mt + (i & 3) + 8 * (i >> 2) + 4 * half;
+      if (row < M) {
+        float v = acc[mt][i] + bco;
+        if (relu_mask) relu_mask[row * DRK_C + co] = v > 0.0f ? 1 : 0;
+        if (relu) v = fmaxf(v, 0.0f);
+        if (resid) v += resid[row * DRK_C + co];
+        out[row * DRK_C + co] = v;
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------ final 128->5 projection
 // 8 lanes per row; lane s takes float4 chunks s, s+8, s+16, s+24 of the row (coalesced), reduces
 // over the 8 lanes by shuffles; lanes 0..4 of the group store one logit each.
@@ -318,8 +404,8 @@ extern "C" int drk_conv_fwd_f32(const float* h, const float* w_pk, const float* 
   ARGCHECK(h && w_pk && out && B >= 0 && L > 0 && taps >= 1 && (taps & 1) && dilation >= 0, "drk_conv_fwd_f32");
   const long M = (long)B * L;
   if (M == 0) return DRK_OK;
-  if (M >= 64L * 512)        // large batches: 64-row tiles (each weight fragment feeds 8 MFMAs)
-    hipLaunchKernelGGL((k_conv_f32<2, false>), dim3((unsigned)((M + 63) / 64)), dim3(256), 0, (hipStream_t)stream, h, w_pk,
+  if (M >= 64L * 512)        // large batches: 64-row tiles, activation rows staged through LDS
+    hipLaunchKernelGGL(k_conv_f32_lds, dim3((unsigned)((M + 63) / 64)), dim3(256), 0, (hipStream_t)stream, h, w_pk,
                        bias, resid, out, relu_mask, M, L, taps, dilation, relu);
   else if (M > 32L * 384)    // 32-row tiles, twice the workgroups
     hipLaunchKernelGGL((k_conv_f32<1, false>), dim3((unsigned)((M + 31) / 32)), dim3(256), 0, (hipStream_t)stream, h, w_pk,
