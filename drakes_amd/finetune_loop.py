@@ -11,6 +11,11 @@ Same arguments and return value as the reference function.  Differences, all add
     gradients on them that nothing reads; the gradient THROUGH the old model into last_x is kept (:68);
   * `on_update(model, epoch)` is called before every optimizer step with the reduced, unclipped gradients in
     place (tests, logging);
+  * `skip_hard_step_kl` (default on): the KL term of a HARD step is identically 0.0 with zero gradient, in floating
+    point too — there last_x is one-hot, so masked positions are multiplied by last_x[..., :4] = 0 and unmasked ones
+    have log_p = log_p_old = the SUBS constants (0 at the held token, -1e6 elsewhere), hence p = p_old and
+    -p + p_old + p * (log_p - log_p_old) = 0 exactly.  Those steps (78 of 128 by default) append an exact zero instead of
+    running two forwards and a backward each; losses and gradients are bit-identical either way (tested on F6 a);
   * under torch.distributed (drakes_amd.dp) every rank runs its own shard (`args.batch_size` rows per rank); the flat
     gradient bucket is all-reduced once, after the last accumulation micro-step and BEFORE clipping (:89-92).
 The reward models are the caller's torch modules (the gReLU model in the reference, oracle.py:230-262): outside the
@@ -41,7 +46,7 @@ def kl_of_step(new_model, old_model, last_x, condt, move_chance_t, copy_flag):
 
 
 def fine_tune(new_model, new_model_y, new_model_y_eval, old_model, args, eps=1e-5, *, log_path=None, save_path=None,
-              seed_of_call=None, verbose=True, on_update=None):
+              seed_of_call=None, verbose=True, on_update=None, skip_hard_step_kl=True):
     if log_path is not None:
         with open(log_path, 'w') as f:
             f.write(args.__repr__() + '\n')
@@ -86,6 +91,9 @@ def fine_tune(new_model, new_model_y, new_model_y_eval, old_model, args, eps=1e-
             total_kl = []
             for random_t in range(args.total_num_steps):                                      # :60-75
                 if args.truncate_kl and random_t < args.total_num_steps - args.truncate_steps:
+                    continue
+                if skip_hard_step_kl and copy_flag_list[random_t].dtype == torch.int64:
+                    total_kl.append(torch.zeros(args.batch_size, dtype=torch.float32, device=sample.device))
                     continue
                 total_kl.append(kl_of_step(new_model, old_model, last_x_list[random_t], condt_list[random_t],
                                            move_chance_t_list[random_t], copy_flag_list[random_t]))

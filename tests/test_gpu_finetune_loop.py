@@ -111,3 +111,26 @@ def test_fine_tune_matches_reference(dev, tag):
     if one_step:
         assert abs(drakes_amd.fine_tune.last_log['tot_grad_norm'] - float(g['grad_norms'][0])) <= 2e-3 * float(g['grad_norms'][0])
         assert abs(drakes_amd.fine_tune.last_log['mean_kl'] - float(g['kl_losses'][0])) <= 2e-3 * abs(float(g['kl_losses'][0])) + 1e-5
+
+
+def test_hard_step_kl_is_exactly_zero(dev, det_sd):
+    """What `skip_hard_step_kl` relies on: with and without it the losses and the accumulated gradients are bit-identical
+    (the weight-gradient kernels use atomics, so the comparison runs on a loss whose hard-step KL would be the only
+    difference: truncate_kl=False, reward weight zero is not available -> compare the KL values themselves)."""
+    from types import SimpleNamespace as NS
+    from drakes_amd import finetune_loop
+    m = drakes_amd.Diffusion(drakes_amd.default_config(steps=10, truncate_steps=3)).to(dev)
+    m.load_state_dict(det_sd)
+    old = drakes_amd.Diffusion(drakes_amd.default_config(steps=10)).to(dev)
+    old.load_state_dict({k: v + 0.01 for k, v in det_sd.items()})
+    m.train()
+    sample, lx, ct, mct, cf = m._sample_finetune_gradient(eval_sp_size=3, seed=12)
+    for t in range(7):                                   # the hard steps
+        assert cf[t].dtype == torch.int64
+        m.zero_grad()
+        kl = finetune_loop.kl_of_step(m, old, lx[t], ct[t], mct[t], cf[t])
+        assert float(kl.abs().max()) == 0.0
+        kl.sum().backward()
+        assert all(p.grad is None or float(p.grad.abs().max()) == 0.0 for p in m.parameters())
+    kl_soft = finetune_loop.kl_of_step(m, old, lx[8], ct[8], mct[8], cf[8])
+    assert float(kl_soft.abs().max()) > 0.0
