@@ -59,6 +59,9 @@ def sample_finetune_gradient(model, num_steps=None, eps=1e-5, eval_sp_size=None,
     bb = model.backbone
     x = model._sample_prior(batch, L).to(dev)
     last_x_list, condt_list, move_chance_t_list, copy_flag_list = [], [], [], []
+    # raw logits (with their graph) of every soft step, keyed by the identity of the state they were computed from: the
+    # fine-tune loop's KL term evaluates the same model on the same tensor (finetune_loop.kl_of_step)
+    model._soft_logits_cache = {}
     shared = None
     for i in range(num_steps):
         _, sigma_t, mc_t, mc_s = table[i]
@@ -80,6 +83,7 @@ def sample_finetune_gradient(model, num_steps=None, eps=1e-5, eval_sp_size=None,
             sig = torch.full((1,), sigma_t if model.time_conditioning else 0.0, dtype=torch.float32, device=dev)
             logits = autograd.backbone_with_grad(bb, x, sig)
             last_x = x
+            model._soft_logits_cache[id(x)] = (x, logits, bb._weights_key())
             x, copy_flag = autograd.soft_step_with_grad(logits, x, mc_t, mc_s, temp, copy_flag_temp, seed, i,
                                                         sample_offset, u)
         last_x_list.append(last_x)

@@ -16,6 +16,8 @@ Same arguments and return value as the reference function.  Differences, all add
     have log_p = log_p_old = the SUBS constants (0 at the held token, -1e6 elsewhere), hence p = p_old and
     -p + p_old + p * (log_p - log_p_old) = 0 exactly.  Those steps (78 of 128 by default) append an exact zero instead of
     running two forwards and a backward each; losses and gradients are bit-identical either way (tested on F6 a);
+  * `reuse_sampling_forward` (default on): see kl_of_step — the KL term of a soft step reuses the logits the sampler
+    computed from the same tensor instead of a second forward/backward of the new model;
   * under torch.distributed (drakes_amd.dp) every rank runs its own shard (`args.batch_size` rows per rank); the flat
     gradient bucket is all-reduced once, after the last accumulation micro-step and BEFORE clipping (:89-92).
 The reward models are the caller's torch modules (the gReLU model in the reference, oracle.py:230-262): outside the
@@ -30,13 +32,23 @@ import torch.nn.functional as F
 from . import autograd, dp
 
 
-def kl_of_step(new_model, old_model, last_x, condt, move_chance_t, copy_flag):
+def kl_of_step(new_model, old_model, last_x, condt, move_chance_t, copy_flag, reuse_sampling_forward=True):
     """kl_div [B] of one recorded reverse step — finetune_reward_bp.py:63-74, one fused kernel each way.
 
     On soft steps last_x carries the sampling graph, so the reference's gradient also runs back through
     old_model.forward(last_x) (:68) into the chain; the frozen model then passes only its input gradient on.  On hard
-    steps last_x is a constant and the frozen model runs without a graph."""
-    log_p_x0 = new_model.forward(last_x, condt)
+    steps last_x is a constant and the frozen model runs without a graph.
+
+    reuse_sampling_forward: `new_model.forward(last_x, condt)` (:67) repeats, on the very same tensor and weights, the
+    denoiser forward that `_sample_finetune_gradient` ran to take that step.  Its raw logits (and their graph) are
+    still there (finetune.sample_finetune_gradient keeps them), so the KL term applies SUBS to them instead of running
+    the network again: one forward and one backward less per soft step; the gradient reaches the weights through the
+    shared node (same value up to fp32 summation order)."""
+    hit = getattr(new_model, '_soft_logits_cache', {}).get(id(last_x)) if reuse_sampling_forward else None
+    if hit is not None and hit[0] is last_x and hit[2] == new_model.backbone._weights_key():
+        log_p_x0 = new_model._subs_parameterization(logits=hit[1], xt=last_x)
+    else:
+        log_p_x0 = new_model.forward(last_x, condt)
     if last_x.requires_grad:
         log_p_x0_old = old_model.forward(last_x, condt)
     else:
@@ -46,7 +58,8 @@ def kl_of_step(new_model, old_model, last_x, condt, move_chance_t, copy_flag):
 
 
 def fine_tune(new_model, new_model_y, new_model_y_eval, old_model, args, eps=1e-5, *, log_path=None, save_path=None,
-              seed_of_call=None, verbose=True, on_update=None, skip_hard_step_kl=True):
+              seed_of_call=None, verbose=True, on_update=None, skip_hard_step_kl=True,
+              reuse_sampling_forward=True):
     if log_path is not None:
         with open(log_path, 'w') as f:
             f.write(args.__repr__() + '\n')
@@ -96,7 +109,7 @@ def fine_tune(new_model, new_model_y, new_model_y_eval, old_model, args, eps=1e-
                     total_kl.append(torch.zeros(args.batch_size, dtype=torch.float32, device=sample.device))
                     continue
                 total_kl.append(kl_of_step(new_model, old_model, last_x_list[random_t], condt_list[random_t],
-                                           move_chance_t_list[random_t], copy_flag_list[random_t]))
+                                           move_chance_t_list[random_t], copy_flag_list[random_t], reuse_sampling_forward))
 
             if epoch_num < args.alpha_schedule_warmup:                                        # :77-81, linear warm-up
                 current_alpha = (epoch_num + 1) / args.alpha_schedule_warmup * args.alpha
