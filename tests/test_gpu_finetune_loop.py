@@ -129,8 +129,8 @@ def test_hard_step_kl_is_exactly_zero(dev, det_sd):
         assert cf[t].dtype == torch.int64
         m.zero_grad()
         kl = finetune_loop.kl_of_step(m, old, lx[t], ct[t], mct[t], cf[t])
-        assert float(kl.abs().max()) == 0.0
+        assert float(kl.detach().abs().max()) == 0.0
         kl.sum().backward()
         assert all(p.grad is None or float(p.grad.abs().max()) == 0.0 for p in m.parameters())
     kl_soft = finetune_loop.kl_of_step(m, old, lx[8], ct[8], mct[8], cf[8])
-    assert float(kl_soft.abs().max()) > 0.0
+    assert float(kl_soft.detach().abs().max()) > 0.0
