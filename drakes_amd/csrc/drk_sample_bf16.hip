@@ -78,6 +78,7 @@ struct SampleArgs {
   const float* uniforms;    // optional [num_steps][B][L][5]
   const int64_t* x_init;    // optional [B][L]; else all-mask prior
   int64_t* x_out;           // [B][L]
+  signed char* traj_out;    // optional [n_fwd][B][L]: the state each forward starts from (what _ddpm_update records)
   float* logits_out;        // optional [B][L][5]: raw logits of forward `dump_fwd`
   int dump_fwd;
   float* dbg_feat;          // optional [B][L][128]: residual stream of forward dump_fwd after layer dbg_layer (-1: stem)
@@ -352,6 +353,7 @@ __device__ __forceinline__ void sample_body(const SampleArgs& a, char* smem, int
 
     // ---- stem: Conv1d(5 -> 128, k = 9) of a one-hot input = the sum of 9 table rows -------------
     __syncthreads();   // tokens / resident tables written above are visible
+    if (a.traj_out && tid < L) a.traj_out[((long)f * a.B + b) * L + tid] = (signed char)tok[tid];
     {
       const int lo_s = opaque(lane);
       const int pn_s = (lo_s & 15) ^ ((lo_s & 8) >> 1);
@@ -549,7 +551,7 @@ __global__ void __launch_bounds__(512, 2) k_sample_bf16(const SampleArgs a) {
 // ------------------------------------------------------------------------------------ C ABI
 extern "C" int drk_sample_bf16(const void* wstream, const void* stem_w, const void* head2_w, const float* vecs, const float* tbias, long tb_fwd_stride,
                                const float* mc_table, const float* uniforms, const int64_t* x_init, int64_t* x_out,
-                               float* logits_out, int dump_fwd, float* dbg_feat, int dbg_layer, int B, int L, int num_steps, int n_layers,
+                               signed char* traj_out, float* logits_out, int dump_fwd, float* dbg_feat, int dbg_layer, int B, int L, int num_steps, int n_layers,
                                const int* dilations, int noise_removal, uint64_t seed, uint64_t sample_offset,
                                void* stream) {
   if (B < 0 || L <= 0) return drk_set_error_msg(DRK_EINVAL, "drk_sample_bf16: bad shape");
@@ -561,7 +563,7 @@ extern "C" int drk_sample_bf16(const void* wstream, const void* stem_w, const vo
     return drk_set_error_msg(DRK_EINVAL, "drk_sample_bf16: null pointer");
   SampleArgs a;
   a.wfrag = (const char*)wstream; a.stem_w = (const char*)stem_w; a.head2_w = (const char*)head2_w; a.vecs = vecs; a.tbias = tbias; a.tb_fwd_stride = tb_fwd_stride;
-  a.mc_table = mc_table; a.uniforms = uniforms; a.x_init = x_init; a.x_out = x_out; a.logits_out = logits_out;
+  a.mc_table = mc_table; a.uniforms = uniforms; a.x_init = x_init; a.x_out = x_out; a.traj_out = traj_out; a.logits_out = logits_out;
   a.dump_fwd = dump_fwd; a.dbg_feat = dbg_feat; a.dbg_layer = dbg_layer; a.B = B; a.L = L; a.num_steps = num_steps; a.n_layers = n_layers;
   a.noise_removal = noise_removal ? 1 : 0; a.seed = seed; a.sample_offset = sample_offset;
   for (int i = 0; i < 4; ++i) a.dilpk[i] = 0;

@@ -69,11 +69,11 @@ def _packed(bb):
 
 
 def _launch(bb, tbias, tb_stride, mc, uniforms, x_init, x_out, logits_out, dump_fwd, B, L, num_steps, noise_removal,
-            seed, sample_offset, dbg_feat=None, dbg_layer=0):
+            seed, sample_offset, dbg_feat=None, dbg_layer=0, traj=None):
     pk = _packed(bb)
     P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
     args = (P(pk['wstream']), P(pk['stem_w']), P(pk['head2_w']), P(pk['vecs']), P(tbias), tb_stride, P(mc), P(uniforms), P(x_init), P(x_out),
-            P(logits_out), dump_fwd, P(dbg_feat), dbg_layer, B, L, num_steps, pk['n_layers'], pk['dil'], 1 if noise_removal else 0, seed,
+            P(traj), P(logits_out), dump_fwd, P(dbg_feat), dbg_layer, B, L, num_steps, pk['n_layers'], pk['dil'], 1 if noise_removal else 0, seed,
             sample_offset, ops._stream())
     flop = 2.0 * B * L * (45 * 128 + pk['n_layers'] * 9 * 128 * 128 + 128 * 128 + 128 * 5) * (num_steps + (1 if noise_removal else 0))
     ops.PROFILE.bracket('k_sample_bf16', flop, lambda: _lib.call('drk_sample_bf16', *args))
@@ -120,3 +120,27 @@ def backbone_logits_bf16(bb, x, sigma_scalar=0.0, dbg_layer=None):
         return logits, out, feat
     _launch(bb, tbias, 0, None, None, x.contiguous(), out, logits, 0, B, L, 0, True, 0, 0)
     return logits, out
+
+
+def hard_steps_bf16(model, batch, table, n_hard, seed, sample_offset, uniforms):
+    """The first `n_hard` reverse steps of a sampling run from the all-mask prior on the fused kernel (no noise removal).
+    Returns (x after those steps int64 [B,L], trajectory int8 [n_hard,B,L] = the state each step started from)."""
+    bb = model.backbone
+    L = model.config.model.length
+    if L > MAX_L:
+        raise NotImplementedError(f'the fused bf16 loop holds L <= {MAX_L}')
+    dev = model.device
+    if model.time_conditioning:
+        tbias = bb.time_bias(torch.tensor([row[1] for row in table[:n_hard]], dtype=torch.float32, device=dev))
+        tb_stride = tbias.stride(0)
+    else:
+        tbias = bb.time_bias(torch.zeros(1, dtype=torch.float32, device=dev))
+        tb_stride = 0
+    mc = torch.tensor([[row[2], row[3]] for row in table[:n_hard]], dtype=torch.float32, device=dev)
+    u = None
+    if uniforms is not None:
+        u = torch.stack([uniforms(i) for i in range(n_hard)]).contiguous()
+    out = torch.empty(batch, L, dtype=torch.int64, device=dev)
+    traj = torch.empty(n_hard, batch, L, dtype=torch.int8, device=dev)
+    _launch(bb, tbias, tb_stride, mc, u, None, out, None, -1, batch, L, n_hard, False, seed, sample_offset, traj=traj)
+    return out, traj

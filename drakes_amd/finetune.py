@@ -63,7 +63,23 @@ def sample_finetune_gradient(model, num_steps=None, eps=1e-5, eval_sp_size=None,
     # fine-tune loop's KL term evaluates the same model on the same tensor (finetune_loop.kl_of_step)
     model._soft_logits_cache = {}
     shared = None
-    for i in range(num_steps):
+    n_hard = max(num_steps - trunc, 0)
+    first = 0
+    if model.hip_dtype == 'bf16' and n_hard > 0 and L <= 224:
+        # hip_dtype = 'bf16': the hard steps carry no gradient (:615-619), so they run as ONE launch of the fused bf16
+        # sampler, which also records the state every step started from; the soft steps stay on the fp32 kernels.
+        # Tokens may differ from the fp32 path's at bf16 level (as for _sample); parity tests use hip_dtype = 'fp32'.
+        from . import fastpath
+        with torch.no_grad():
+            x, traj = fastpath.hard_steps_bf16(model, batch, table, n_hard, seed, sample_offset, uniforms)
+            for i in range(n_hard):
+                xi = traj[i].to(torch.int64)
+                last_x_list.append(F.one_hot(xi, num_classes=model.vocab_size).to(torch.float32))
+                condt_list.append(torch.full((batch,), table[i][1], dtype=torch.float32, device=dev))
+                move_chance_t_list.append(torch.full((batch, 1, 1), table[i][2], dtype=torch.float32, device=dev))
+                copy_flag_list.append((xi != model.mask_index).to(torch.int64).unsqueeze(-1))
+        first = n_hard
+    for i in range(first, num_steps):
         _, sigma_t, mc_t, mc_s = table[i]
         u = uniforms(i) if uniforms is not None else None
         condt = torch.full((batch,), sigma_t, dtype=torch.float32, device=dev)

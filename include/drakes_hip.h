@@ -203,23 +203,23 @@ int drk_kl_step_bwd(const float* logp, const float* logp_old, const float* last_
  * num_steps x (CNNModel.forward + _subs_parameterization + _ddpm_update tail) and, if
  * noise_removal, the final forward + argmax (:541-549).  One workgroup per sequence; L <= 224.
  *   wstream   bf16 weight stages: n_layers*9 conv taps + final_conv.0 (layout: drakes_amd/fastpath.py::pack_stream)
- *   stem_w    bf16 [128][64] stem weights, head2_w bf16 [8][128] final_conv.2 weights (same file)
+ *   stem_w    bf16 [46][128] stem gather table (row 5*tap + v, row 45 zero), head2_w bf16 [8][128] final_conv.2 weights (same file)
  *   vecs      float32 [n_layers+1][3][128] biases and LayerNorm affine terms (same file)
  *   tbias     float32 [n_tb][n_layers][128] time biases (drk_time_bias_fwd); forward f reads row
  *             f * tb_fwd_stride / (n_layers*128) (stride 0: time_conditioning=False)
  *   mc_table  float32 [num_steps][2] = (move_chance_t, move_chance_s) per step
  *   uniforms  NULL (in-kernel Philox) or float32 [num_steps][B][L][5]
  *   x_init    NULL (all-mask prior, :438-440) or int64 [B][L];  x_out int64 [B][L]
+ *   traj_out  NULL or int8 [num_steps (+1 with noise removal)][B][L]: the state every forward starts from (what
+ *             _sample_finetune_gradient records as last_x / copy_flag on its hard steps, :615-619)
  *   logits_out NULL or float32 [B][L][5]: raw logits of forward number dump_fwd (tests)
  *   dbg_feat  NULL or float32 [B][L][128]: residual stream of forward dump_fwd after layer
  *             dbg_layer (-1 = after the stem) (tests)
  * num_steps may be 0 with noise_removal=1: one forward + argmax from x_init. */
 int drk_sample_bf16(const void* wstream, const void* stem_w, const void* head2_w, const float* vecs, const float* tbias, long tb_fwd_stride,
                     const float* mc_table, const float* uniforms, const int64_t* x_init, int64_t* x_out,
-                    float* logits_out, int dump_fwd, float* dbg_feat, int dbg_layer, int B, int L,
-                    int num_steps, int n_layers,
-                    const int* dilations, int noise_removal, uint64_t seed, uint64_t sample_offset,
-                    void* stream);
+                    signed char* traj_out, float* logits_out, int dump_fwd, float* dbg_feat, int dbg_layer, int B, int L, int num_steps, int n_layers,
+                    const int* dilations, int noise_removal, uint64_t seed, uint64_t sample_offset, void* stream);
 
 #ifdef __cplusplus
 }

@@ -168,3 +168,31 @@ def test_sample_finetune_gradient_golden(dev, det_sd, tag):
             assert e < 5e-3, (name, e)
     gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m.parameters() if p.grad is not None)).item()
     assert abs(gn - float(g['grad_norm'])) <= 2e-3 * float(g['grad_norm']), (gn, float(g['grad_norm']))
+
+
+def test_sample_finetune_gradient_bf16_hard_phase(dev, det_sd):
+    """hip_dtype='bf16': the gradient-free hard steps run as one launch of the fused sampler, which records the state each
+    step started from; the soft steps and everything differentiable stay fp32."""
+    steps, trunc, B = 24, 6, 4
+    m = drakes_amd.Diffusion(drakes_amd.default_config(steps=steps, truncate_steps=trunc)).to(dev)
+    m.load_state_dict(det_sd)
+    m.train()
+    ref = m._sample_finetune_gradient(eval_sp_size=B, seed=77)
+    m.hip_dtype = 'bf16'
+    out, lx, ct, mct, cf = m._sample_finetune_gradient(eval_sp_size=B, seed=77)
+    n_hard = steps - trunc
+    assert len(lx) == len(ct) == len(mct) == len(cf) == steps and out.requires_grad
+    assert float(lx[0][..., 4].min()) == 1.0                              # starts all-masked
+    for i in range(n_hard):
+        assert lx[i].shape == (B, 200, 5) and cf[i].shape == (B, 200, 1) and cf[i].dtype == torch.int64
+        assert torch.equal(cf[i].squeeze(-1), (lx[i].argmax(-1) != 4).long())
+        assert torch.equal(ct[i], ref[2][i]) and torch.equal(mct[i], ref[3][i])
+        if i:
+            keep = cf[i - 1].squeeze(-1).bool()                           # carry-over: an unmasked token never changes
+            assert torch.equal(lx[i].argmax(-1)[keep], lx[i - 1].argmax(-1)[keep])
+    # same noise, bf16 logits: the recorded trajectory stays close to the fp32 one
+    mism = float((lx[n_hard].argmax(-1) != ref[1][n_hard].argmax(-1)).float().mean())
+    print('token mismatch vs fp32 hard phase after', n_hard, 'steps:', mism)
+    assert mism < 0.05
+    (out.sum(-1) * torch.randn(B, 200, device=dev)).sum().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters() if p.requires_grad)
