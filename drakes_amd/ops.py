@@ -161,7 +161,7 @@ def conv_fwd_f32(h, w_pk, bias, resid, dilation, relu=True, out=None, relu_mask=
     args = (_f(h, 'h'), _f(w_pk, 'w_pk'), _f(bias, 'bias'), _f(resid, 'resid'), _f(out, 'out'),
             _dev_ptr(relu_mask, torch.uint8, 'relu_mask'), B, L, taps, dilation, 1 if relu else 0, _stream())
     if taps == 9:
-        PROFILE.bracket('k_conv_f32_lds' if B * L >= 32768 else 'k_conv_f32<1>', 2.0 * B * L * C * C * taps, lambda: _lib.call('drk_conv_fwd_f32', *args))
+        PROFILE.bracket('k_conv_f32_lds' if B * L >= 16384 else 'k_conv_f32<1>', 2.0 * B * L * C * C * taps, lambda: _lib.call('drk_conv_fwd_f32', *args))
     else:
         _lib.call('drk_conv_fwd_f32', *args)
     return out
