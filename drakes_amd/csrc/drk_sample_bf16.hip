@@ -164,6 +164,135 @@ __device__ __forceinline__ void mma_tap(const char* smem, const char* __restrict
   }
 }
 
+// ---- layers with dead tiles: straight-line taps with COMPILE-TIME live ranges ------------------------------------
+// With dilation 16 and 64 many (tile, tap) pairs multiply nothing but padding: a tile whose 16 shifted rows all fall
+// outside [0, L) (53 % of the pairs at dilation 64, 17 % at 16, 12 % of a whole forward).  Skipping them under a
+// runtime test does not pay (a wave-uniform branch per tile makes the compiler drain the LDS queue at every join;
+// a switch over variants spills).  But for 192 < L <= 208 and shifts that are multiples of 16 the live tiles of every
+// tap are known at compile time: tile T (positions 16T..16T+15) is live for shift `off` iff 16T + off <= 192 (off > 0)
+// or 16T + 15 >= -off (off < 0).  The dead tiles of a wave are a prefix or a suffix of its tiles, so a tap is a static
+// range [T0, T1), and a layer is 2m+1 different instantiations in a row: no branch, no join, exact LDS-read counts.
+__host__ __device__ constexpr int live_lo(int off, int grp, int nt) {   // first live t of the wave's tiles T = grp + 2t
+  int t = 0;
+  while (t < nt && off < 0 && 16 * (grp + 2 * t) + 15 < -off) ++t;
+  return t;
+}
+__host__ __device__ constexpr int live_hi(int off, int grp, int nt) {   // one past the last live t
+  int t = nt;
+  while (t > 0 && off > 0 && 16 * (grp + 2 * (t - 1)) + off > 192) --t;
+  return t < live_lo(off, grp, nt) ? live_lo(off, grp, nt) : t;
+}
+
+// One tap over the static tile range [T0, T1); during the last k-step the k-step-0 fragments of the NEXT tap's range
+// [N0, N1) are fetched (shift off_next).  Otherwise as mma_tap.
+template <int NT, int T0, int T1, int N0, int N1>
+__device__ __forceinline__ void mma_tap_static(const char* smem, const char* __restrict__ wnext, bf16v8 (&ring)[8],
+                                               int off_next, int L, int lane, int grp, const char* (&bp)[NT],
+                                               bf16v8 (&cur)[NT], f32x4 (&acc)[NT][2]) {
+  const int lo = opaque(lane);
+  const int pn = (lo & 15) ^ ((lo & 8) >> 1);
+  const char* hb = smem + OFF_HB + 128 * ((lo >> 4) & 1) + 64 * (lo >> 5);
+  auto next_row = [&](int t) {
+    const int pp = 16 * (grp + 2 * t) + pn + off_next;
+    return hb + (((unsigned)pp < (unsigned)L) ? pp : ZROW) * ROWB;
+  };
+  if constexpr (T1 - T0 >= 1 && T1 - T0 <= 2) {
+    // One or two live tiles: 2-4 MFMAs per k-step cannot cover an LDS read, so all of the tap's fragments are
+    // requested up front (the k-step-0 ones are in cur[] already) and one latency is paid instead of three.
+    constexpr int NL = T1 - T0;
+    bf16v8 f[3][NL];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int t = 0; t < NL; ++t) f[k][t] = *(const bf16v8*)(bp[T0 + t] + 16 * (k + 1));
+#pragma unroll
+    for (int t = N0; t < N1; ++t) {
+      bp[t] = next_row(t);
+      if (t < T0 || t >= T1) cur[t] = *(const bf16v8*)(bp[t]);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const bf16v8 a0 = ring[2 * ks], a1 = ring[2 * ks + 1];
+#pragma unroll
+      for (int t = 0; t < NL; ++t) {
+        const bf16v8 b = (ks == 0) ? cur[T0 + t] : f[ks - 1][t];
+        acc[T0 + t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b, acc[T0 + t][0], 0, 0, 0);
+        acc[T0 + t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b, acc[T0 + t][1], 0, 0, 0);
+      }
+      ring[2 * ks] = *(const bf16v8*)(wnext + ks * KSTEP_BYTES);
+      ring[2 * ks + 1] = *(const bf16v8*)(wnext + ks * KSTEP_BYTES + SUB_BYTES);
+    }
+#pragma unroll
+    for (int t = T0; t < T1; ++t)
+      if (t >= N0 && t < N1) cur[t] = *(const bf16v8*)(bp[t]);
+    return;
+  }
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const bf16v8 a0 = ring[2 * ks], a1 = ring[2 * ks + 1];
+    if (ks + 1 == 4) {   // tiles that only the next tap uses
+#pragma unroll
+      for (int t = N0; t < N1; ++t)
+        if (t < T0 || t >= T1) {
+          bp[t] = next_row(t);
+          cur[t] = *(const bf16v8*)(bp[t]);
+        }
+    }
+#pragma unroll
+    for (int t = T0; t < T1; ++t) {
+      acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, cur[t], acc[t][0], 0, 0, 0);
+      acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, cur[t], acc[t][1], 0, 0, 0);
+      if (ks + 1 < 4) {
+        cur[t] = *(const bf16v8*)(bp[t] + 16 * (ks + 1));
+      } else if (t >= N0 && t < N1) {
+        bp[t] = next_row(t);
+        cur[t] = *(const bf16v8*)(bp[t]);
+      }
+    }
+    ring[2 * ks] = *(const bf16v8*)(wnext + ks * KSTEP_BYTES);
+    ring[2 * ks + 1] = *(const bf16v8*)(wnext + ks * KSTEP_BYTES + SUB_BYTES);
+    // pinned issue order, as in mma_tap: (reads of tiles only the next tap uses,) then per live tile two MFMAs and the
+    // read that replaces its fragment, then the two ring refills
+    if (ks + 1 == 4) {
+      constexpr int extra = (N1 - N0) - ((T1 < N1 ? T1 : N1) - (T0 > N0 ? T0 : N0) > 0 ? (T1 < N1 ? T1 : N1) - (T0 > N0 ? T0 : N0) : 0);
+      if (extra > 0) __builtin_amdgcn_sched_group_barrier(0x100, extra, 0);
+    }
+#pragma unroll
+    for (int t = T0; t < T1; ++t) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      if (ks + 1 < 4 || (t >= N0 && t < N1)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+  }
+}
+
+// Taps K .. M of a layer with static dilation D (shift K*D), each with its own live range; wn = this lane's pointer to
+// the weights of tap K+1, wafter = to the tap that follows the layer's last.
+template <int NT, int GRP, int D, int M, int K>
+__device__ __forceinline__ void static_taps(const char* smem, const char* wn, const char* wafter, bf16v8 (&ring)[8], int L,
+                                            int lane, const char* (&bp)[NT], bf16v8 (&cur)[NT], f32x4 (&acc)[NT][2]) {
+  constexpr int off = K * D, offn = (K + 1) * D;
+  constexpr bool last = (K == M);
+  constexpr int T0 = live_lo(off, GRP, NT), T1 = live_hi(off, GRP, NT);
+  constexpr int N0 = last ? 0 : live_lo(offn, GRP, NT), N1 = last ? 0 : live_hi(offn, GRP, NT);
+  mma_tap_static<NT, T0, T1, N0, N1>(smem, last ? wafter : wn, ring, offn, L, lane, GRP, bp, cur, acc);
+  if constexpr (!last) static_taps<NT, GRP, D, M, K + 1>(smem, wn + TAP_BYTES, wafter, ring, L, lane, bp, cur, acc);
+}
+
+// Whole MMA phase of such a layer: first tap's fragments (the only exposed LDS latency), then the taps.
+template <int NT, int GRP, int D, int M>
+__device__ __forceinline__ void static_layer(const char* smem, const char* wn, const char* wafter, bf16v8 (&ring)[8], int L,
+                                             int lane, f32x4 (&acc)[NT][2]) {
+  constexpr int T0 = live_lo(-M * D, GRP, NT), T1 = live_hi(-M * D, GRP, NT);
+  const char* bp[NT];
+  bf16v8 cur[NT];
+  tap_rows<NT>(smem, -M * D, L, lane, GRP, bp);
+#pragma unroll
+  for (int t = T0; t < T1; ++t) cur[t] = *(const bf16v8*)(bp[t]);
+  if (T1 > T0) __builtin_amdgcn_sched_group_barrier(0x100, T1 - T0, 0);   // the k-step-0 reads first, as a group
+  static_taps<NT, GRP, D, M, -M>(smem, wn, wafter, ring, L, lane, bp, cur, acc);
+}
+
 // This lane's channels: 32 ct + 16 s + 4 g + i (s = 0,1; i = 0..3) <-> register [s][i].
 __device__ __forceinline__ void load_vec8(const float* v, int ch0, f32x4 (&o)[2]) {
   o[0] = *(const f32x4*)(v + ch0);
@@ -299,10 +428,12 @@ __device__ __forceinline__ void dump_feat(float* __restrict__ dst, long b, int L
 
 // The body, specialised on the number of position tiles this wave owns (7 for waves 0-3, 6 or 7 for
 // waves 4-7).  Positions >= L inside a computed tile are never stored.
-template <int NT, int NTHR>
+template <int NT, int GRP, int NTHR>
 __device__ __forceinline__ void sample_body(const SampleArgs& a, char* smem, int tid, int wave, int lane) {
-  const int ct = wave & 3, grp = wave >> 2;
+  const int ct = wave & 3;
+  constexpr int grp = GRP;
   const int L = a.L;
+  const bool static_ok = (L > 192 && L <= 208);   // 13 tiles: the live ranges of static_layer hold
   const int ntiles = (L + 15) >> 4;
   const long b = blockIdx.x;
   const uint64_t sample = a.sample_offset + (uint64_t)b;
@@ -394,17 +525,30 @@ __device__ __forceinline__ void sample_body(const SampleArgs& a, char* smem, int
         acc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f};
         acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
-      const char* bp[NT];
-      bf16v8 cur[NT];
-      int off = -m * dil;
       const char* wn = wlane + (long)(9 * layer + 4 - m + 1) * TAP_BYTES;
-      tap_begin<NT>(smem, off, L, lane, grp, bp, cur);
-      for (int k = 0; k < 2 * m; ++k) {
-        off += dil;
-        mma_tap<NT, true>(smem, wn, ring, off, L, lane, grp, bp, cur, acc);
-        wn += TAP_BYTES;
+      const char* wafter = wlane + (long)after * TAP_BYTES;
+      bool done = false;
+      if constexpr ((NT == 7 && GRP == 0) || (NT == 6 && GRP == 1)) {
+        if (static_ok && dil == 64) {          // m == 3
+          static_layer<NT, GRP, 64, 3>(smem, wn, wafter, ring, L, lane, acc);
+          done = true;
+        } else if (static_ok && dil == 16) {   // m == 4
+          static_layer<NT, GRP, 16, 4>(smem, wn, wafter, ring, L, lane, acc);
+          done = true;
+        }
       }
-      mma_tap<NT, false>(smem, wlane + (long)after * TAP_BYTES, ring, 0, L, lane, grp, bp, cur, acc);
+      if (!done) {
+        const char* bp[NT];
+        bf16v8 cur[NT];
+        int off = -m * dil;
+        tap_begin<NT>(smem, off, L, lane, grp, bp, cur);
+        for (int k = 0; k < 2 * m; ++k) {
+          off += dil;
+          mma_tap<NT, true>(smem, wn, ring, off, L, lane, grp, bp, cur, acc);
+          wn += TAP_BYTES;
+        }
+        mma_tap<NT, false>(smem, wafter, ring, 0, L, lane, grp, bp, cur, acc);
+      }
       ACCUM(0, t0);
       epilogue_ln<NT, false>(smem, feat, acc, vecs + 384 * (layer + 1), tbl + 128 * (layer + 1), layer + 1 < a.n_layers,
                              L, lane, ct, grp);
@@ -541,11 +685,11 @@ __global__ void __launch_bounds__(512, 2) k_sample_bf16(const SampleArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: scalar branches, SGPR tile ids
   if (wave < 4)
-    sample_body<7, 512>(a, smem, tid, wave, lane);
+    sample_body<7, 0, 512>(a, smem, tid, wave, lane);
   else if (a.L <= 208)
-    sample_body<6, 512>(a, smem, tid, wave, lane);
+    sample_body<6, 1, 512>(a, smem, tid, wave, lane);
   else
-    sample_body<7, 512>(a, smem, tid, wave, lane);
+    sample_body<7, 1, 512>(a, smem, tid, wave, lane);
 }
 
 // ------------------------------------------------------------------------------------ C ABI

@@ -143,7 +143,8 @@ class Diffusion(nn.Module):
             seed = self._draw_seed()
         table, sigma_last, _, _ = noise_schedule.step_table(self.noise, num_steps, eps)
         table = table.tolist()
-        x = self._sample_prior(batch, L).to(dev)
+        # _sample_prior (:438-440) built on the device: a host-to-device copy would wait for every kernel queued before it
+        x = torch.full((batch, L), self.mask_index, dtype=torch.int64, device=dev)
         if batch == 0:
             return x
         if self.hip_dtype == 'bf16':

@@ -89,14 +89,22 @@ def sample_bf16(model, x, table, sigma_last, seed, sample_offset, uniforms):
     dev = x.device
     num_steps = len(table)
     noise_removal = bool(model.config.sampling.noise_removal)
-    if model.time_conditioning:
-        sig = [row[1] for row in table] + [sigma_last]
-        tbias = bb.time_bias(torch.tensor(sig, dtype=torch.float32, device=dev))
-        tb_stride = tbias.stride(0)
-    else:
-        tbias = bb.time_bias(torch.zeros(1, dtype=torch.float32, device=dev))
-        tb_stride = 0
-    mc = torch.tensor([[row[2], row[3]] for row in table], dtype=torch.float32, device=dev)
+    # Schedule tensors live on the device across calls: a host-to-device copy from pageable memory waits for the
+    # kernels already queued on the stream, which would serialise every call's host work behind the previous launch.
+    key = (num_steps, table[0][1] if table else 0.0, table[-1][3] if table else 0.0, sigma_last, model.time_conditioning,
+           bb._weights_key(), str(dev))
+    cache = getattr(model, '_sched_cache', None)
+    if cache is None or cache[0] != key:
+        if model.time_conditioning:
+            sig = [row[1] for row in table] + [sigma_last]
+            tbias = bb.time_bias(torch.tensor(sig, dtype=torch.float32, device=dev))
+            tb_stride = tbias.stride(0)
+        else:
+            tbias = bb.time_bias(torch.zeros(1, dtype=torch.float32, device=dev))
+            tb_stride = 0
+        mc = torch.tensor([[row[2], row[3]] for row in table], dtype=torch.float32, device=dev)
+        model._sched_cache = cache = (key, tbias, tb_stride, mc)
+    _, tbias, tb_stride, mc = cache
     u = None
     if uniforms is not None:
         u = torch.stack([uniforms(i) for i in range(num_steps)]).contiguous()

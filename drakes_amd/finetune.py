@@ -57,7 +57,7 @@ def sample_finetune_gradient(model, num_steps=None, eps=1e-5, eval_sp_size=None,
     table, _, _, _ = noise_schedule.step_table(model.noise, num_steps, eps)
     table = table.tolist()
     bb = model.backbone
-    x = model._sample_prior(batch, L).to(dev)
+    x = torch.full((batch, L), model.mask_index, dtype=torch.int64, device=dev)      # _sample_prior, on the device
     last_x_list, condt_list, move_chance_t_list, copy_flag_list = [], [], [], []
     # raw logits (with their graph) of every soft step, keyed by the identity of the state they were computed from: the
     # fine-tune loop's KL term evaluates the same model on the same tensor (finetune_loop.kl_of_step)

@@ -23,7 +23,7 @@ from oracle import philox
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize('B,L', [(4, 200), (3, 64), (2, 33), (1, 224), (5, 9)])
+@pytest.mark.parametrize('B,L', [(4, 200), (3, 64), (2, 33), (1, 224), (5, 9), (2, 192), (2, 193), (2, 208), (2, 209)])
 def test_fused_forward_logits(gpu_model, dev, det_sd, B, L):
     gen = np.random.Generator(np.random.PCG64(100 + L))
     x = torch.from_numpy(gen.integers(0, 5, (B, L)))
