@@ -71,8 +71,7 @@ class _BackboneFn(torch.autograd.Function):
         dw0 = _zeros(1, C, C, like=y)
         db0 = _zeros(1, C, like=y)
         if want_w:
-            ops.conv_wgrad_f32(feats[n], dpre, dw0, 0)
-            ops.colsum128(dpre, 1, M, db0)
+            ops.conv_wgrad_f32(feats[n], dpre, dw0, 0, db0[0])
         gr = ops.conv_fwd_f32(dpre, pk['head0_wT'], None, None, 0, relu=False)
         g['final_conv.2.weight'], g['final_conv.2.bias'] = dw2.unsqueeze(-1), db2
         g['final_conv.0.weight'], g['final_conv.0.bias'] = dw0.permute(2, 1, 0), db0[0]
@@ -86,23 +85,19 @@ class _BackboneFn(torch.autograd.Function):
             d = bb.dilation(i)
             ops.mask_mul(gr, masks[i], out=dc)
             if want_w:
-                g[f'convs.{i}.bias'] = ops.colsum128(dc, 1, M, _zeros(1, C, like=y))[0]
                 ops.ln_fwd(feats[i], ctx.tbias[0, i], ctx.tb_stride, pk['ln_g'][i], pk['ln_b'][i], out=h)
-                dwt = _zeros(9, C, C, like=y)
-                ops.conv_wgrad_f32(h, dc, dwt, d)
-                g[f'convs.{i}.weight'] = dwt.permute(2, 1, 0)
+                dwt, dbias = _zeros(9, C, C, like=y), _zeros(C, like=y)
+                ops.conv_wgrad_f32(h, dc, dwt, d, dbias)          # the bias gradient rides on the centre tap
+                g[f'convs.{i}.weight'], g[f'convs.{i}.bias'] = dwt.permute(2, 1, 0), dbias
             ops.conv_fwd_f32(dc, pk['conv_wT'][i], None, None, d, relu=False, out=dh)
             dgam, dbet = _zeros(C, like=y), _zeros(C, like=y)
             gnew = torch.empty_like(y)
+            shared_tb = want_w and not ctx.tb_stride          # one time-bias row for the batch: its gradient is fused in
             ops.ln_bwd(dh, feats[i], ctx.tbias[0, i], ctx.tb_stride, pk['ln_g'][i], means[i], rstds[i], gr, dxin, gnew,
-                       dgam, dbet)
+                       dgam, dbet, dtb[i, 0] if shared_tb else None)
             g[f'norms.{i}.weight'], g[f'norms.{i}.bias'] = dgam, dbet
-            if not want_w:
-                pass
-            elif ctx.tb_stride:
+            if want_w and ctx.tb_stride:
                 ops.colsum128(dxin, B, L, dtb[i])
-            else:
-                ops.colsum128(dxin, 1, M, dtb[i])
             gr = gnew
         # stem
         dpre = ops.relu_bwd(gr, feats[0], out=gr)

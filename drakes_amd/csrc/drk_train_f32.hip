@@ -65,11 +65,12 @@ __global__ void __launch_bounds__(256) k_ln_bwd(const float* __restrict__ dh, co
                                                 const float* __restrict__ gamma, const float* __restrict__ mean,
                                                 const float* __restrict__ rstd, const float* __restrict__ g_resid,
                                                 float* __restrict__ dxin, float* __restrict__ dfeat,
-                                                float* __restrict__ dgamma, float* __restrict__ dbeta, long M, int L) {
-  __shared__ float pg[8][128], pb[8][128];
+                                                float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                float* __restrict__ dtb, long M, int L) {
+  __shared__ float pg[8][128], pb[8][128], px[8][128];
   const int lr = threadIdx.x & 31, sub = threadIdx.x >> 5;
   const f32x4 gm = *(const f32x4*)(gamma + 4 * lr);
-  f32x4 ag = {0.f, 0.f, 0.f, 0.f}, ab = {0.f, 0.f, 0.f, 0.f};
+  f32x4 ag = {0.f, 0.f, 0.f, 0.f}, ab = {0.f, 0.f, 0.f, 0.f}, ax = {0.f, 0.f, 0.f, 0.f};
   for (long row = (long)blockIdx.x * 64 + sub; row < (long)blockIdx.x * 64 + 64 && row < M; row += 8) {
     const long b = row / L;
     f32x4 x = *(const f32x4*)(feat + row * DRK_C + 4 * lr);
@@ -93,9 +94,11 @@ __global__ void __launch_bounds__(256) k_ln_bwd(const float* __restrict__ dh, co
     *(f32x4*)(dfeat + row * DRK_C + 4 * lr) = o;
     ag += d * xh;
     ab += d;
+    ax += dx;
   }
   *(f32x4*)(&pg[sub][4 * lr]) = ag;
   *(f32x4*)(&pb[sub][4 * lr]) = ab;
+  *(f32x4*)(&px[sub][4 * lr]) = ax;
   __syncthreads();
   if (threadIdx.x < 128) {
     float sg = 0.f, sb = 0.f;
@@ -106,6 +109,12 @@ __global__ void __launch_bounds__(256) k_ln_bwd(const float* __restrict__ dh, co
     }
     atomicAdd(dgamma + threadIdx.x, sg);
     atomicAdd(dbeta + threadIdx.x, sb);
+    if (dtb) {   // gradient of a time bias shared by the whole batch = column sum of dxin
+      float sx = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) sx += px[k][threadIdx.x];
+      atomicAdd(dtb + threadIdx.x, sx);
+    }
   }
 }
 
@@ -118,7 +127,8 @@ __global__ void __launch_bounds__(256) k_ln_bwd(const float* __restrict__ dh, co
 // workgroup reduces `wg_rows` rows with f32 MFMAs (K = 2 rows per instruction) and adds its 128x128 partial with fp32
 // atomics.  wg_rows is chosen by the host so that small batches still fill the chip.
 __global__ void __launch_bounds__(256) k_conv_wgrad(const float* __restrict__ h, const float* __restrict__ dc,
-                                                    float* __restrict__ dwt, long M, int L, int taps, int dil, int wg_rows) {
+                                                    float* __restrict__ dwt, float* __restrict__ dbias, long M, int L, int taps, int dil,
+                                                    int wg_rows) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int half = lane >> 5, lr = lane & 31;
   const int t = blockIdx.y;
@@ -151,6 +161,8 @@ __global__ void __launch_bounds__(256) k_conv_wgrad(const float* __restrict__ h,
   };
   float a0, a1, a2, a3;
   f32x4 b0, b1, b2, b3;
+  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};   // column sums of dc = the conv bias gradient (one wave of the centre-tap workgroup)
+  const bool do_bias = dbias && off == 0 && t == taps / 2 && w == 0;
   fetch(0, a0, b0);
   fetch(1, a1, b1);
   fetch(2, a2, b2);
@@ -158,15 +170,26 @@ __global__ void __launch_bounds__(256) k_conv_wgrad(const float* __restrict__ h,
     fetch(s + 3, a3, b3);
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0[j], acc[j], 0, 0, 0);
+    if (do_bias) bsum += b0;
     fetch(s + 4, a0, b0);
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1[j], acc[j], 0, 0, 0);
+    if (do_bias) bsum += b1;
     fetch(s + 5, a1, b1);
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2[j], acc[j], 0, 0, 0);
+    if (do_bias) bsum += b2;
     fetch(s + 6, a2, b2);
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, b3[j], acc[j], 0, 0, 0);
+    if (do_bias) bsum += b3;
+  }
+  if (do_bias) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float v = bsum[j] + __shfl_xor(bsum[j], 32);      // even + odd rows
+      if (half == 0) atomicAdd(dbias + 32 * j + lr, v);
+    }
   }
   float* dst = dwt + (long)t * DRK_C * DRK_C;
 #pragma unroll
@@ -699,18 +722,18 @@ extern "C" int drk_colsum128(const float* x, float* out, long n_seg, long seg_ro
 
 extern "C" int drk_ln_bwd(const float* dh, const float* feat, const float* tbias, long tbias_bstride, const float* gamma,
                           const float* mean, const float* rstd, const float* g_resid, float* dxin, float* dfeat,
-                          float* dgamma, float* dbeta, int B, int L, void* stream) {
+                          float* dgamma, float* dbeta, float* dtbias_shared, int B, int L, void* stream) {
   DRK_SHAPE_GUARD("drk_ln_bwd");
   ARGCHECK(dh && feat && gamma && mean && rstd && dxin && dfeat && dgamma && dbeta, "drk_ln_bwd");
   const long M = (long)B * L;
   hipLaunchKernelGGL(k_ln_bwd, dim3((unsigned)((M + 63) / 64)), dim3(256), 0, (hipStream_t)stream, dh, feat, tbias,
-                     tbias_bstride, gamma, mean, rstd, g_resid, dxin, dfeat, dgamma, dbeta, M, L);
+                     tbias_bstride, gamma, mean, rstd, g_resid, dxin, dfeat, dgamma, dbeta, dtbias_shared, M, L);
   DRK_CHECK_LAUNCH();
   return DRK_OK;
 }
 
-extern "C" int drk_conv_wgrad_f32(const float* h, const float* dc, float* dwt, int B, int L, int taps, int dilation,
-                                  void* stream) {
+extern "C" int drk_conv_wgrad_f32(const float* h, const float* dc, float* dwt, float* dbias, int B, int L, int taps,
+                                  int dilation, void* stream) {
   DRK_SHAPE_GUARD("drk_conv_wgrad_f32");
   ARGCHECK(h && dc && dwt && taps >= 1 && (taps & 1) && dilation >= 0, "drk_conv_wgrad_f32");
   const long M = (long)B * L;
@@ -718,7 +741,7 @@ extern "C" int drk_conv_wgrad_f32(const float* h, const float* dc, float* dwt, i
   int wg_rows = 512;
   while (wg_rows > 64 && ((M + wg_rows - 1) / wg_rows) * taps < 512) wg_rows >>= 1;
   hipLaunchKernelGGL(k_conv_wgrad, dim3((unsigned)((M + wg_rows - 1) / wg_rows), (unsigned)taps), dim3(256), 0,
-                     (hipStream_t)stream, h, dc, dwt, M, L, taps, dilation, wg_rows);
+                     (hipStream_t)stream, h, dc, dwt, dbias, M, L, taps, dilation, wg_rows);
   DRK_CHECK_LAUNCH();
   return DRK_OK;
 }

@@ -193,18 +193,19 @@ def colsum128(x, n_seg, seg_rows, out):
     return out
 
 
-def ln_bwd(dh, feat, tbias_layer, tb_stride, gamma, mean, rstd, g_resid, dxin, dfeat, dgamma, dbeta):
+def ln_bwd(dh, feat, tbias_layer, tb_stride, gamma, mean, rstd, g_resid, dxin, dfeat, dgamma, dbeta, dtb_shared=None):
     B, L, _ = feat.shape
     tb = ctypes.c_void_p(tbias_layer.data_ptr()) if tbias_layer is not None else None
     _lib.call('drk_ln_bwd', _f(dh, 'dh'), _f(feat, 'feat'), tb, tb_stride, _f(gamma, 'gamma'), _f(mean, 'mean'),
               _f(rstd, 'rstd'), _f(g_resid, 'g_resid'), _f(dxin, 'dxin'), _f(dfeat, 'dfeat'), _f(dgamma, 'dgamma'),
-              _f(dbeta, 'dbeta'), B, L, _stream())
+              _f(dbeta, 'dbeta'), _f(dtb_shared, 'dtbias_shared'), B, L, _stream())
 
 
-def conv_wgrad_f32(h, dc, dwt, dilation):
-    """dwt [taps,128(ci),128(co)] += ..."""
+def conv_wgrad_f32(h, dc, dwt, dilation, dbias=None):
+    """dwt [taps,128(ci),128(co)] += ...; dbias [128] += column sums of dc (optional)."""
     B, L, _ = h.shape
-    _lib.call('drk_conv_wgrad_f32', _f(h, 'h'), _f(dc, 'dc'), _f(dwt, 'dwt'), B, L, dwt.shape[0], dilation, _stream())
+    _lib.call('drk_conv_wgrad_f32', _f(h, 'h'), _f(dc, 'dc'), _f(dwt, 'dwt'), _f(dbias, 'dbias'), B, L, dwt.shape[0], dilation,
+              _stream())
 
 
 def head_out_bwd(dlogits, y, w, dy, dw, db):

@@ -147,12 +147,15 @@ int drk_mask_mul(const float* g, const unsigned char* mask, float* out, long n, 
 int drk_relu_bwd(const float* g, const float* y, float* out, long n, void* stream);
 /* out[seg][128] += column sums of x[seg*seg_rows .. +seg_rows][128] (bias / time-bias gradients). */
 int drk_colsum128(const float* x, float* out, long n_seg, long seg_rows, void* stream);
-/* LayerNorm backward of drk_ln_fwd: dxin, dfeat = dxin + g_resid (g_resid may be NULL), dgamma/dbeta accumulated. */
+/* LayerNorm backward of drk_ln_fwd: dxin, dfeat = dxin + g_resid (g_resid may be NULL), dgamma/dbeta accumulated;
+ * dtbias_shared (optional, float32 [128], accumulated): the column sum of dxin = the gradient of a time bias that one
+ * row serves the whole batch with (tbias_bstride == 0). */
 int drk_ln_bwd(const float* dh, const float* feat, const float* tbias, long tbias_bstride, const float* gamma,
                const float* mean, const float* rstd, const float* g_resid, float* dxin, float* dfeat,
-               float* dgamma, float* dbeta, int B, int L, void* stream);
-/* Conv1d weight gradient: dwt[t][ci][co] += sum_rows h[row + (t - taps/2)*dilation][ci] * dc[row][co]. */
-int drk_conv_wgrad_f32(const float* h, const float* dc, float* dwt, int B, int L, int taps, int dilation,
+               float* dgamma, float* dbeta, float* dtbias_shared, int B, int L, void* stream);
+/* Conv1d weight gradient: dwt[t][ci][co] += sum_rows h[row + (t - taps/2)*dilation][ci] * dc[row][co].  dbias (optional, float32 [128], accumulated): column sums of dc,
+ * the conv bias gradient, taken by the centre-tap workgroups on the way. */
+int drk_conv_wgrad_f32(const float* h, const float* dc, float* dwt, float* dbias, int B, int L, int taps, int dilation,
                        void* stream);
 /* Backward of drk_head_out_fwd: dy [B][L][128]; dw [5][128], db [5] accumulated. */
 int drk_head_out_bwd(const float* dlogits, const float* y, const float* w, float* dy, float* dw, float* db,
