@@ -50,6 +50,8 @@ SIGNATURES = {
     'drk_kl_step_fwd': [_P, _P, _P, _P, _P, c_float, _P, c_int, c_int, _P],
     'drk_kl_step_bwd': [_P, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P, c_int, c_int, _P],
     'drk_head_out_fwd': [_P, _P, _P, _P, c_int, c_int, _P],
+    'drk_layer_bf16': [_P, _P, _P, _P, _P, _P, _P, c_long, _P, _P, c_int, c_int, c_int, c_int, c_int, _P],
+    'drk_ln_fwd_bf16': [_P, _P, c_long, _P, _P, _P, c_int, c_int, _P],
     'drk_sample_bf16': [_P, _P, _P, _P, _P, c_long, _P, _P, _P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, c_int,
                         c_uint64, c_uint64, _P],
 }

@@ -1,0 +1,278 @@
+// drk_layer_bf16 — ONE residual layer of the CNN denoiser (models/dnaconv.py:88-97) per launch, bf16 MFMA, for shapes
+// the fused sampler cannot hold in LDS (L > 224: BASELINE.json configs[4], 1024-bp sequences) and for batched
+// forwards:
+//     feat' = feat + relu(conv_dilated(h) + bias)                      (fp32, global, in place allowed)
+//     h'    = bf16( LayerNorm(feat' + tbias') * gamma' + beta' )       (the NEXT layer's input), or bf16(feat')
+// h is the bf16 LayerNorm output of the previous launch ([rows][128], rows = B*L flattened).  A workgroup owns 128
+// consecutive rows x all 128 output channels, so the LayerNorm of its rows completes inside it.
+//   * MFMA v_mfma_f32_16x16x32_bf16, A = weights [16 co][32 ci] straight from L2 in fragment order (the SAME packed
+//     stream and k-slot <-> channel map as drk_sample_bf16, fastpath.py::pack_stream), 8-deep register ring;
+//   * B = activations: each tap's 128 shifted rows are fetched as whole 256-byte rows (coalesced), parked in LDS with
+//     272-byte rows (conflict-free ds_read_b128 with the column permutation of drk_sample_bf16), double-buffered: the
+//     next tap's rows are in flight in registers under this tap's 64 MFMAs per wave.  Rows whose shifted position
+//     leaves [0, L) (or the batch) are zeros: 'same' padding and the sequence boundary in one test;
+//   * epilogue: bias + ReLU + residual (feat read and written as 16-byte pieces), LayerNorm statistics by
+//     v_permlane32_swap / v_permlane16_swap + four partials through LDS, h' staged in LDS and written out as rows.
+// HBM per row and layer: 256 B (h) + 512 B + 512 B (feat in/out) + 256 B (h') against 295 kFLOP: compute-bound.
+#include "drk_common.h"
+#include "../../include/drakes_hip.h"
+
+typedef __bf16 bf16v8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16v4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+#define LT_ROWS 128              // rows per workgroup = 8 position tiles of 16
+#define LT_NT 8
+#define LT_ROWB 272              // LDS row: 128 bf16 + 16 B pad
+#define LT_TAP_BYTES 32768       // [4 k-steps][4 ct][2 s][64 lanes][16 B]
+#define LT_KSTEP_BYTES 8192
+#define LT_SUB_BYTES 1024
+#define LT_PART_STRIDE 12        // floats per row in the LayerNorm partial buffer (8 used)
+
+struct LayerArgs {
+  const char* h;            // bf16 [M][128]
+  const float* feat;        // fp32 [M][128] residual input (NULL: no residual, head conv)
+  float* feat_out;          // fp32 [M][128]
+  char* h_out;              // bf16 [M][128] (NULL: not needed)
+  const char* wfrag;        // this layer's taps in fragment order
+  const float* bias;        // [128]
+  const float* tbias;       // next LayerNorm's time bias [128] per batch row (stride tb_stride) or shared; NULL with ln = 0
+  long tb_stride;
+  const float* gamma;       // next LayerNorm's affine [128] (ln = 1)
+  const float* beta;
+  long M;
+  int L, taps, dil, first_tap, ln;
+};
+
+__global__ void __launch_bounds__(256, 2) k_layer_bf16(const LayerArgs a) {
+  __shared__ __attribute__((aligned(16))) char tile[2][LT_ROWS * LT_ROWB];
+  __shared__ __attribute__((aligned(16))) float part[LT_ROWS * LT_PART_STRIDE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int ct = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 15, g = lane >> 4;
+  const int pn = n ^ ((n & 8) >> 1);
+  const int goff = 128 * (g & 1) + 64 * (g >> 1);
+  const long r0 = (long)blockIdx.x * LT_ROWS;
+  const int L = a.L;
+
+  // staging role: rows srow + 16 i (i < 8), 16-byte chunk scol
+  const int srow = tid >> 4, scol = tid & 15;
+  int spos[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) spos[i] = (int)((r0 + srow + 16 * i) % L);
+  f32x4 stage[8];
+  auto fetch = [&](int off) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const long row = r0 + srow + 16 * i;
+      const int p = spos[i] + off;
+      stage[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (row < a.M && p >= 0 && p < L) stage[i] = *(const f32x4*)(a.h + (row + off) * 256 + 16 * scol);
+    }
+  };
+  auto park = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) *(f32x4*)(&tile[buf][(srow + 16 * i) * LT_ROWB + 16 * scol]) = stage[i];
+  };
+
+  f32x4 acc[LT_NT][2];
+#pragma unroll
+  for (int t = 0; t < LT_NT; ++t) {
+    acc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const int center = a.taps / 2;
+  const int last_tap = a.taps - 1 - a.first_tap;          // live taps: first_tap .. taps-1-first_tap (shift < L)
+  const char* wlane = a.wfrag + ct * (2 * LT_SUB_BYTES) + lane * 16;
+  bf16v8 ring[8];
+#pragma unroll
+  for (int f = 0; f < 8; ++f)
+    ring[f] = *(const bf16v8*)(wlane + (long)a.first_tap * LT_TAP_BYTES + (f >> 1) * LT_KSTEP_BYTES + (f & 1) * LT_SUB_BYTES);
+  fetch((a.first_tap - center) * a.dil);
+  park(0);
+  __syncthreads();
+
+  for (int tap = a.first_tap; tap <= last_tap; ++tap) {
+    const int buf = (tap - a.first_tap) & 1;
+    const bool more = tap < last_tap;
+    if (more) fetch((tap + 1 - center) * a.dil);           // in flight under this tap's MFMAs
+    const char* wnext = wlane + (long)(more ? tap + 1 : tap) * LT_TAP_BYTES;   // (after the last tap the refill is unused)
+    const char* base = &tile[buf][pn * LT_ROWB + goff];
+    bf16v8 cur[LT_NT];
+#pragma unroll
+    for (int t = 0; t < LT_NT; ++t) cur[t] = *(const bf16v8*)(base + 16 * t * LT_ROWB);
+    __builtin_amdgcn_sched_group_barrier(0x100, LT_NT, 0);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const bf16v8 a0 = ring[2 * ks], a1 = ring[2 * ks + 1];
+#pragma unroll
+      for (int t = 0; t < LT_NT; ++t) {
+        acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, cur[t], acc[t][0], 0, 0, 0);
+        acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, cur[t], acc[t][1], 0, 0, 0);
+        if (ks + 1 < 4) cur[t] = *(const bf16v8*)(base + 16 * t * LT_ROWB + 16 * (ks + 1));
+      }
+      ring[2 * ks] = *(const bf16v8*)(wnext + ks * LT_KSTEP_BYTES);
+      ring[2 * ks + 1] = *(const bf16v8*)(wnext + ks * LT_KSTEP_BYTES + LT_SUB_BYTES);
+#pragma unroll
+      for (int t = 0; t < LT_NT; ++t) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        if (ks + 1 < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+    }
+    if (more) {
+      park(buf ^ 1);       // the other buffer: its readers finished before the previous barrier
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue ---------------------------------------------------------------------------------------------------
+  {
+#pragma clang fp contract(fast)
+  const int ch0 = 32 * ct + 4 * g;
+  const f32x4 cb0 = *(const f32x4*)(a.bias + ch0), cb1 = *(const f32x4*)(a.bias + ch0 + 16);
+  f32x4 x[LT_NT][2];
+#pragma unroll
+  for (int t = 0; t < LT_NT; ++t) {
+    const long row = r0 + 16 * t + pn;
+    const bool ok = row < a.M;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const f32x4 cb = s ? cb1 : cb0;
+      f32x4 r;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) r[i] = fmaxf(acc[t][s][i] + cb[i], 0.f);
+      if (a.feat && ok) r += *(const f32x4*)(a.feat + row * DRK_C + ch0 + 16 * s);
+      if (ok) *(f32x4*)(a.feat_out + row * DRK_C + ch0 + 16 * s) = r;
+      x[t][s] = r;
+    }
+  }
+  if (!a.h_out) return;
+  __syncthreads();   // every wave is past its reads of the activation tiles: tile[0] becomes the h' staging area
+  if (a.ln) {
+    float y[LT_NT];
+#pragma unroll
+    for (int t = 0; t < LT_NT; ++t) {
+      const long row = r0 + 16 * t + pn;
+      const long brow = (row < a.M ? row : a.M - 1) / L;
+      const float* tb = a.tbias + brow * a.tb_stride + ch0;
+      const f32x4 t0 = *(const f32x4*)(tb), t1 = *(const f32x4*)(tb + 16);
+      x[t][0] += t0;
+      x[t][1] += t1;
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          s1 += x[t][s][i];
+          s2 += x[t][s][i] * x[t][s][i];
+        }
+      const u32x2 sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(s1), __float_as_uint(s2), false, false);
+      y[t] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    }
+    const int slot = (g >> 1) * 4 + ct;
+#pragma unroll
+    for (int t = 0; t < LT_NT; t += 2) {
+      const u32x2 sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(y[t]), __float_as_uint(y[t + 1]), false, false);
+      const int tile_i = (g & 1) ? t + 1 : t;
+      part[(16 * tile_i + pn) * LT_PART_STRIDE + slot] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    }
+    const f32x4 g0 = *(const f32x4*)(a.gamma + ch0), g1 = *(const f32x4*)(a.gamma + ch0 + 16);
+    const f32x4 b0 = *(const f32x4*)(a.beta + ch0), b1 = *(const f32x4*)(a.beta + ch0 + 16);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < LT_NT; ++t) {
+      const float* pp = part + (16 * t + pn) * LT_PART_STRIDE;
+      const f32x4 q1 = *(const f32x4*)(pp), q2 = *(const f32x4*)(pp + 4);
+      const float s1 = (q1[0] + q1[1]) + (q1[2] + q1[3]);
+      const float s2 = (q2[0] + q2[1]) + (q2[2] + q2[3]);
+      const float mean = s1 * (1.0f / 128.0f);
+      const float var = fmaxf(s2 * (1.0f / 128.0f) - mean * mean, 0.0f);
+      const float rstd = __builtin_amdgcn_rsqf(var + 1e-5f);
+      const float c = -mean * rstd;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        x[t][0][i] = (x[t][0][i] * rstd + c) * g0[i] + b0[i];
+        x[t][1][i] = (x[t][1][i] * rstd + c) * g1[i] + b1[i];
+      }
+    }
+  }
+  // h' tile -> LDS (natural channel order), then out as whole rows
+#pragma unroll
+  for (int t = 0; t < LT_NT; ++t) {
+    char* row = &tile[0][(16 * t + pn) * LT_ROWB + 2 * ch0];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16v4 pk;
+      pk[0] = (__bf16)x[t][s][0]; pk[1] = (__bf16)x[t][s][1]; pk[2] = (__bf16)x[t][s][2]; pk[3] = (__bf16)x[t][s][3];
+      *(bf16v4*)(row + 32 * s) = pk;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const long row = r0 + srow + 16 * i;
+    if (row < a.M) *(f32x4*)(a.h_out + row * 256 + 16 * scol) = *(const f32x4*)(&tile[0][(srow + 16 * i) * LT_ROWB + 16 * scol]);
+  }
+  }
+}
+
+// LayerNorm(feat + tbias) * gamma + beta -> bf16 rows: the first layer's input (after the stem).  32 lanes per row.
+__global__ void __launch_bounds__(256) k_ln_bf16(const float* __restrict__ feat, const float* __restrict__ tbias, long tb_stride,
+                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                 char* __restrict__ h, long M, int L) {
+  const int lr = threadIdx.x & 31;
+  const long row = (long)blockIdx.x * 8 + (threadIdx.x >> 5);
+  if (row >= M) return;
+  f32x4 v = *(const f32x4*)(feat + row * DRK_C + 4 * lr);
+  if (tbias) v += *(const f32x4*)(tbias + (row / L) * tb_stride + 4 * lr);
+  float s1 = (v[0] + v[1]) + (v[2] + v[3]);
+  float s2 = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+#pragma unroll
+  for (int o = 16; o >= 1; o >>= 1) {
+    s1 += __shfl_xor(s1, o);
+    s2 += __shfl_xor(s2, o);
+  }
+  const float mean = s1 * (1.0f / 128.0f);
+  const float var = fmaxf(s2 * (1.0f / 128.0f) - mean * mean, 0.0f);
+  const float rstd = __builtin_amdgcn_rsqf(var + 1e-5f);
+  const f32x4 gm = *(const f32x4*)(gamma + 4 * lr), be = *(const f32x4*)(beta + 4 * lr);
+  bf16v4 pk;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) pk[i] = (__bf16)(((v[i] - mean) * rstd) * gm[i] + be[i]);
+  *(bf16v4*)(h + row * 256 + 8 * lr) = pk;
+}
+
+#define LARGCHECK(cond, name) \
+  if (!(cond)) return drk_set_error_msg(DRK_EINVAL, name ": bad arguments")
+
+extern "C" int drk_layer_bf16(const void* h, const float* feat, float* feat_out, void* h_out, const void* wfrag,
+                              const float* bias, const float* tbias, long tb_stride, const float* gamma,
+                              const float* beta, int B, int L, int taps, int dilation, int ln, void* stream) {
+  DRK_SHAPE_GUARD("drk_layer_bf16");
+  LARGCHECK(h && feat_out && wfrag && bias && taps >= 1 && (taps & 1) && dilation >= 0, "drk_layer_bf16");
+  LARGCHECK(!ln || (h_out && tbias && gamma && beta), "drk_layer_bf16 (LayerNorm parameters)");
+  LayerArgs a;
+  a.h = (const char*)h; a.feat = feat; a.feat_out = feat_out; a.h_out = (char*)h_out; a.wfrag = (const char*)wfrag;
+  a.bias = bias; a.tbias = tbias; a.tb_stride = tb_stride; a.gamma = gamma; a.beta = beta;
+  a.M = (long)B * L; a.L = L; a.taps = taps; a.dil = dilation; a.ln = ln ? 1 : 0;
+  // taps whose shift is >= L read only padding at every position: skipped (as in drk_sample_bf16)
+  const int center = taps / 2;
+  int reach = center;
+  if (dilation > 0 && (L - 1) / dilation < reach) reach = (L - 1) / dilation;
+  a.first_tap = center - reach;
+  hipLaunchKernelGGL(k_layer_bf16, dim3((unsigned)((a.M + LT_ROWS - 1) / LT_ROWS)), dim3(256), 0, (hipStream_t)stream, a);
+  DRK_CHECK_LAUNCH();
+  return DRK_OK;
+}
+
+extern "C" int drk_ln_fwd_bf16(const float* feat, const float* tbias, long tb_stride, const float* gamma, const float* beta,
+                               void* h, int B, int L, void* stream) {
+  DRK_SHAPE_GUARD("drk_ln_fwd_bf16");
+  LARGCHECK(feat && gamma && beta && h, "drk_ln_fwd_bf16");
+  const long M = (long)B * L;
+  hipLaunchKernelGGL(k_ln_bf16, dim3((unsigned)((M + 7) / 8)), dim3(256), 0, (hipStream_t)stream, feat, tbias, tb_stride, gamma,
+                     beta, (char*)h, M, L);
+  DRK_CHECK_LAUNCH();
+  return DRK_OK;
+}

@@ -147,23 +147,27 @@ class Diffusion(nn.Module):
         x = torch.full((batch, L), self.mask_index, dtype=torch.int64, device=dev)
         if batch == 0:
             return x
+        bb = self.backbone
+        fwd = bb.forward_f32
         if self.hip_dtype == 'bf16':
             from . import fastpath
-            return fastpath.sample_bf16(self, x, table, float(sigma_last), seed, sample_offset, uniforms)
-        bb = self.backbone
+            if L <= fastpath.MAX_L:
+                return fastpath.sample_bf16(self, x, table, float(sigma_last), seed, sample_offset, uniforms)
+            # longer sequences do not fit one workgroup's LDS: one bf16-MFMA launch per residual layer, same step kernels
+            fwd = lambda seq, tb, stride, work: fastpath.forward_bf16_layers(bb, seq, tb, stride, work)
         shared = None if self.time_conditioning else self._shared_time_bias(0.0)
-        if self.hip_graph and uniforms is None and shared is not None and num_steps > 0:
+        if self.hip_graph and uniforms is None and shared is not None and num_steps > 0 and fwd == bb.forward_f32:
             x = self._sample_graph(x, table, shared, seed, sample_offset)
             num_steps = 0                      # the loop below is skipped; noise removal follows
         for i in range(num_steps):
             _, sigma_t, mc_t, mc_s = table[i]
             tb = shared if shared is not None else self._shared_time_bias(sigma_t)
-            logits = bb.forward_f32(x, tb, 0, self._work)
+            logits = fwd(x, tb, 0, self._work)
             u = uniforms(i) if uniforms is not None else None
             ops.reverse_step_hard(logits, x, mc_t, mc_s, seed, i, sample_offset, u, out=x)
         if self.config.sampling.noise_removal:
             tb = shared if shared is not None else self._shared_time_bias(float(sigma_last))
-            logits = bb.forward_f32(x, tb, 0, self._work)
+            logits = fwd(x, tb, 0, self._work)
             x = ops.denoise_argmax(logits, x)
         return x
 

@@ -152,3 +152,49 @@ def hard_steps_bf16(model, batch, table, n_hard, seed, sample_offset, uniforms):
     traj = torch.empty(n_hard, batch, L, dtype=torch.int8, device=dev)
     _launch(bb, tbias, tb_stride, mc, u, None, out, None, -1, batch, L, n_hard, False, seed, sample_offset, traj=traj)
     return out, traj
+
+
+# ---- layer-per-launch bf16 path (any length) ------------------------------------------------------------------------
+def _bf16_ptr(t, name):
+    if t is None:
+        return None
+    if not t.is_cuda or t.dtype != torch.bfloat16 or not t.is_contiguous():
+        raise TypeError(f'{name}: expected a contiguous bfloat16 tensor on the GPU')
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def forward_bf16_layers(bb, seq, tbias, tb_stride, work=None):
+    """Raw logits [B,L,5] of the denoiser with one bf16-MFMA launch per residual layer (drk_layer_bf16): the path for
+    sequences longer than the fused sampler's 224 positions.  Rounding points of the fused kernel in the residual stack
+    and the first head conv (bf16 weights and LayerNorm outputs, fp32 accumulation and residual stream); stem and the
+    128 -> 5 output conv run on the exact-fp32 kernels.  seq int64 [B,L] or float32 [B,L,5];
+    tbias [nb, n_layers, 128] with tb_stride floats between batch rows (0: one row for the batch)."""
+    pk, st = bb.packed(), _packed(bb)
+    B, L = seq.shape[0], seq.shape[1]
+    n = bb.num_layers
+    if work is None:
+        work = {}
+    def buf(name, dtype, *shape):
+        t = work.get(name)
+        if t is None or t.shape != torch.Size(shape) or t.dtype != dtype:
+            t = torch.empty(*shape, dtype=dtype, device=seq.device)
+            work[name] = t
+        return t
+    feat = ops.stem_fwd(seq, pk['stem_w'], pk['stem_b'], out=buf('feat', torch.float32, B, L, ops.C))
+    h = [buf('h0', torch.bfloat16, B, L, ops.C), buf('h1', torch.bfloat16, B, L, ops.C)]
+    fp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    vec = st['vecs']                               # [(n+1)*3, 128]: see pack_stream
+    _lib.call('drk_ln_fwd_bf16', fp(feat), fp(tbias[0, 0]), tb_stride, fp(vec[1]), fp(vec[2]), _bf16_ptr(h[0], 'h'), B, L,
+              ops._stream())
+    flop = 2.0 * B * L * 9 * ops.C * ops.C
+    for i in range(n):
+        last = i + 1 == n
+        w_i = st['wstream'][9 * i:]
+        args = (_bf16_ptr(h[i & 1], 'h'), fp(feat), fp(feat), _bf16_ptr(h[(i + 1) & 1], 'h_out'), fp(w_i), fp(vec[3 * (i + 1)]),
+                None if last else fp(tbias[0, i + 1]), tb_stride, None if last else fp(vec[3 * (i + 1) + 1]),
+                None if last else fp(vec[3 * (i + 1) + 2]), B, L, 9, bb.dilation(i), 0 if last else 1, ops._stream())
+        ops.PROFILE.bracket('k_layer_bf16', flop, lambda: _lib.call('drk_layer_bf16', *args))
+    y = buf('y', torch.float32, B, L, ops.C)
+    _lib.call('drk_layer_bf16', _bf16_ptr(h[n & 1], 'h'), None, fp(y), None, fp(st['wstream'][9 * n:]), fp(vec[3 * n + 1]),
+              None, 0, None, None, B, L, 1, 0, 0, ops._stream())
+    return ops.head_out_fwd(y, pk['head2_w'], pk['head2_b'], out=buf('logits', torch.float32, B, L, ops.V))

@@ -224,6 +224,20 @@ int drk_sample_bf16(const void* wstream, const void* stem_w, const void* head2_w
                     signed char* traj_out, float* logits_out, int dump_fwd, float* dbg_feat, int dbg_layer, int B, int L, int num_steps, int n_layers,
                     const int* dilations, int noise_removal, uint64_t seed, uint64_t sample_offset, void* stream);
 
+/* ---- one residual layer per launch, bf16 MFMA (any L; BASELINE.json configs[4]: 1024-bp sequences) ---------------
+ * models/dnaconv.py:88-97 for one layer:  feat_out = feat + relu(conv_dilated(h) + bias)   (feat NULL: no residual — the
+ * head's final_conv.0, :104), and, when h_out is not NULL, the NEXT layer's input
+ * h_out = bf16(LayerNorm(feat_out + tbias) * gamma + beta) (ln = 1) or bf16(feat_out) (ln = 0).
+ * h, h_out: bf16 [B*L][128], distinct buffers (neighbouring workgroups read h while h_out is written);
+ * feat, feat_out: float32 [B*L][128] (may alias); wfrag: this layer's taps in the fragment order of
+ * drakes_amd/fastpath.py::pack_stream; tbias: [128] of batch row 0, tb_stride floats between rows (0: shared). */
+int drk_layer_bf16(const void* h, const float* feat, float* feat_out, void* h_out, const void* wfrag, const float* bias,
+                   const float* tbias, long tb_stride, const float* gamma, const float* beta, int B, int L, int taps,
+                   int dilation, int ln, void* stream);
+/* h = bf16(LayerNorm(feat + tbias) * gamma + beta): the first layer's input (dnaconv.py:92-93). */
+int drk_ln_fwd_bf16(const float* feat, const float* tbias, long tb_stride, const float* gamma, const float* beta, void* h,
+                    int B, int L, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
