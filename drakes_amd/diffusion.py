@@ -156,8 +156,8 @@ class Diffusion(nn.Module):
             # longer sequences do not fit one workgroup's LDS: one bf16-MFMA launch per residual layer, same step kernels
             fwd = lambda seq, tb, stride, work: fastpath.forward_bf16_layers(bb, seq, tb, stride, work)
         shared = None if self.time_conditioning else self._shared_time_bias(0.0)
-        if self.hip_graph and uniforms is None and shared is not None and num_steps > 0 and fwd == bb.forward_f32:
-            x = self._sample_graph(x, table, shared, seed, sample_offset)
+        if self.hip_graph and uniforms is None and shared is not None and num_steps > 0:
+            x = self._sample_graph(x, table, shared, seed, sample_offset, fwd)
             num_steps = 0                      # the loop below is skipped; noise removal follows
         for i in range(num_steps):
             _, sigma_t, mc_t, mc_s = table[i]
@@ -171,7 +171,7 @@ class Diffusion(nn.Module):
             x = ops.denoise_argmax(logits, x)
         return x
 
-    def _sample_graph(self, x, table, shared, seed, sample_offset):
+    def _sample_graph(self, x, table, shared, seed, sample_offset, fwd):
         """The step loop of _sample as ONE captured launch sequence (hipGraph), replayed once per step: the launches of
         a step (denoiser forward + fused reverse step) are recorded once per (batch, length); what changes from step to
         step or call to call (move chances, the Philox step index, seed) is read from device memory by the step kernel.  Removes the
@@ -180,7 +180,7 @@ class Diffusion(nn.Module):
         num_steps = len(table)
         dev = x.device
         mc = torch.tensor([[row[2], row[3]] for row in table], dtype=torch.float32, device=dev)
-        key = (B, L, num_steps, shared.data_ptr(), self.backbone._weights_key())
+        key = (B, L, num_steps, shared.data_ptr(), self.backbone._weights_key(), self.hip_dtype)
         st = self._graph
         if st is None or st['key'] != key:
             st = {'key': key, 'x': torch.empty_like(x), 'counter': torch.zeros(1, dtype=torch.int32, device=dev), 'mc': mc,
@@ -191,11 +191,11 @@ class Diffusion(nn.Module):
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):          # warm-up outside capture: allocates the work buffers
-                logits = self.backbone.forward_f32(st['x'], shared, 0, work)
+                logits = fwd(st['x'], shared, 0, work)
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                logits = self.backbone.forward_f32(st['x'], shared, 0, work)
+                logits = fwd(st['x'], shared, 0, work)
                 ops.reverse_step_hard_table(logits, st['x'], st['mc'], st['counter'], st['rng'], out=st['x'])
             st['graph'], st['work'] = graph, work
             self._graph = st

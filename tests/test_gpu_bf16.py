@@ -216,5 +216,9 @@ def test_long_sequences_take_the_layer_path(dev, det_sd):
     rate = (a != b).float().mean().item()
     print('L=1024, bf16 layer path vs fp32 kernels: token mismatch', rate)
     assert rate < 0.25
+    m.hip_graph = True                                # the captured step loop replays the same kernels: same tokens
+    assert torch.equal(m._sample(eval_sp_size=3, seed=21).cpu(), b)
+    assert torch.equal(m._sample(eval_sp_size=3, seed=22).cpu()[1:], m._sample(eval_sp_size=2, seed=22, sample_offset=1).cpu())
+    m.hip_graph = False
     with pytest.raises(NotImplementedError):
         fastpath.sample_bf16(m, torch.full((1, 1024), 4, dtype=torch.int64, device=dev), [], 0.0, 0, 0, None)
