@@ -7,13 +7,16 @@
 // consecutive rows x all 128 output channels, so the LayerNorm of its rows completes inside it.
 //   * MFMA v_mfma_f32_16x16x32_bf16, A = weights [16 co][32 ci] straight from L2 in fragment order (the SAME packed
 //     stream and k-slot <-> channel map as drk_sample_bf16, fastpath.py::pack_stream), 8-deep register ring;
-//   * B = activations: each tap's 128 shifted rows are fetched as whole 256-byte rows (coalesced), parked in LDS with
-//     272-byte rows (conflict-free ds_read_b128 with the column permutation of drk_sample_bf16), double-buffered: the
-//     next tap's rows are in flight in registers under this tap's 64 MFMAs per wave.  Rows whose shifted position
-//     leaves [0, L) (or the batch) are zeros: 'same' padding and the sequence boundary in one test;
+//   * B = activations, parked in LDS with 272-byte rows (conflict-free ds_read_b128 with the column permutation of
+//     drk_sample_bf16).  Dilation <= 16: the 128 rows and their halo (up to 64 rows either side) are fetched ONCE as
+//     whole 256-byte rows, a tap is a row offset, a lane whose shifted position leaves [0, L) reads an all-zero row
+//     ('same' padding and the sequence boundary in one test), no barrier inside the tap loop, and the fp32 residual is
+//     fetched ahead of the loop.  Dilation 64: each tap's 128 shifted rows are fetched separately, double-buffered,
+//     the next tap's rows in flight in registers under this tap's 64 MFMAs per wave;
 //   * epilogue: bias + ReLU + residual (feat read and written as 16-byte pieces), LayerNorm statistics by
 //     v_permlane32_swap / v_permlane16_swap + four partials through LDS, h' staged in LDS and written out as rows.
-// HBM per row and layer: 256 B (h) + 512 B + 512 B (feat in/out) + 256 B (h') against 295 kFLOP: compute-bound.
+// HBM per row and layer: 256 B (h) + 512 B + 512 B (fp32 residual in/out) + 256 B (h') = 1536 B against 295 kFLOP =
+// 192 FLOP/B, below the machine balance (312 FLOP/B): HBM-bound once the tensors outgrow the 256 MB Infinity Cache.
 #include "drk_common.h"
 #include "../../include/drakes_hip.h"
 
@@ -44,9 +47,19 @@ struct LayerArgs {
   int L, taps, dil, first_tap, ln;
 };
 
-__global__ void __launch_bounds__(256, 2) k_layer_bf16(const LayerArgs a) {
-  __shared__ __attribute__((aligned(16))) char tile[2][LT_ROWS * LT_ROWB];
-  __shared__ __attribute__((aligned(16))) float part[LT_ROWS * LT_PART_STRIDE];
+// LDS: TROWS rows of 272 B (two 128-row tap buffers, or one halo tile), then the LayerNorm partials, whose first 272
+// bytes are the all-zero row of HALO mode until the epilogue.
+
+// HALO (128 + 2 * reach rows fit the tile: dilation <= 16 with nine taps): the workgroup's rows and their halo are
+// fetched ONCE; a tap is a row offset, and a lane whose shifted position leaves [0, L) reads the all-zero row instead
+// (sequence boundaries fall anywhere inside a tile).  No barrier inside the tap loop.
+// !HALO (dilation 64): each tap's 128 shifted rows are fetched separately, double-buffered.
+template <bool HALO, int TROWS, int WGS, bool PRE>
+__global__ void __launch_bounds__(256, WGS) k_layer_bf16(const LayerArgs a) {
+  constexpr int LT_TILE_BYTES = TROWS * LT_ROWB, LT_ZERO_OFF = LT_TILE_BYTES;
+  __shared__ __attribute__((aligned(16))) char smem[LT_TILE_BYTES + LT_ROWS * LT_PART_STRIDE * 4];
+  char* const tile0 = smem;
+  float* const part = (float*)(smem + LT_TILE_BYTES);
   const int tid = threadIdx.x, lane = tid & 63;
   const int ct = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = lane & 15, g = lane >> 4;
@@ -54,26 +67,11 @@ __global__ void __launch_bounds__(256, 2) k_layer_bf16(const LayerArgs a) {
   const int goff = 128 * (g & 1) + 64 * (g >> 1);
   const long r0 = (long)blockIdx.x * LT_ROWS;
   const int L = a.L;
+  const unsigned p0 = (unsigned)(r0 % L);               // position of the tile's first row in its sequence
 
   // staging role: rows srow + 16 i (i < 8), 16-byte chunk scol
   const int srow = tid >> 4, scol = tid & 15;
-  int spos[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) spos[i] = (int)((r0 + srow + 16 * i) % L);
   f32x4 stage[8];
-  auto fetch = [&](int off) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const long row = r0 + srow + 16 * i;
-      const int p = spos[i] + off;
-      stage[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (row < a.M && p >= 0 && p < L) stage[i] = *(const f32x4*)(a.h + (row + off) * 256 + 16 * scol);
-    }
-  };
-  auto park = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) *(f32x4*)(&tile[buf][(srow + 16 * i) * LT_ROWB + 16 * scol]) = stage[i];
-  };
 
   f32x4 acc[LT_NT][2];
 #pragma unroll
@@ -88,48 +86,138 @@ __global__ void __launch_bounds__(256, 2) k_layer_bf16(const LayerArgs a) {
 #pragma unroll
   for (int f = 0; f < 8; ++f)
     ring[f] = *(const bf16v8*)(wlane + (long)a.first_tap * LT_TAP_BYTES + (f >> 1) * LT_KSTEP_BYTES + (f & 1) * LT_SUB_BYTES);
-  fetch((a.first_tap - center) * a.dil);
-  park(0);
-  __syncthreads();
 
-  for (int tap = a.first_tap; tap <= last_tap; ++tap) {
-    const int buf = (tap - a.first_tap) & 1;
-    const bool more = tap < last_tap;
-    if (more) fetch((tap + 1 - center) * a.dil);           // in flight under this tap's MFMAs
-    const char* wnext = wlane + (long)(more ? tap + 1 : tap) * LT_TAP_BYTES;   // (after the last tap the refill is unused)
-    const char* base = &tile[buf][pn * LT_ROWB + goff];
+  // HALO has the registers to fetch the fp32 residual ahead of the tap loop instead of in the epilogue
+  const int ch0 = 32 * ct + 4 * g;
+  f32x4 res[PRE ? LT_NT : 1][2];
+  if constexpr (HALO) {
+    const int halo = center * a.dil;
+    const int rows_total = LT_ROWS + 2 * halo;            // <= 256, checked by the entry point
+    if (tid < LT_ROWB / 16) *(f32x4*)(smem + LT_ZERO_OFF + 16 * tid) = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < rows_total; c += LT_ROWS) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int lr = c + srow + 16 * i;
+        const long row = r0 - halo + lr;
+        stage[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (lr < rows_total && row >= 0 && row < a.M) stage[i] = *(const f32x4*)(a.h + row * 256 + 16 * scol);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int lr = c + srow + 16 * i;
+        if (lr < rows_total) *(f32x4*)(tile0 + lr * LT_ROWB + 16 * scol) = stage[i];
+      }
+    }
+    __syncthreads();
+    // the fp32 residual of this lane's outputs: in flight under the whole tap loop
+#pragma unroll
+    for (int t = 0; t < (PRE ? LT_NT : 0); ++t) {
+      const long row = r0 + 16 * t + pn;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        res[t][s] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (a.feat && row < a.M) res[t][s] = *(const f32x4*)(a.feat + row * DRK_C + ch0 + 16 * s);
+      }
+    }
+    int pos[LT_NT];
+#pragma unroll
+    for (int t = 0; t < LT_NT; ++t) pos[t] = (int)((p0 + 16 * t + pn) % (unsigned)L);
+    const int own = (halo + pn) * LT_ROWB + goff;         // this lane's row of tile 0, unshifted
+    auto addr_of = [&](int t, int s) {
+      return (unsigned)(pos[t] + s) < (unsigned)L ? own + (16 * t + s) * LT_ROWB : LT_ZERO_OFF + goff;
+    };
+    int cura[LT_NT];
     bf16v8 cur[LT_NT];
 #pragma unroll
-    for (int t = 0; t < LT_NT; ++t) cur[t] = *(const bf16v8*)(base + 16 * t * LT_ROWB);
-    __builtin_amdgcn_sched_group_barrier(0x100, LT_NT, 0);
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const bf16v8 a0 = ring[2 * ks], a1 = ring[2 * ks + 1];
-#pragma unroll
-      for (int t = 0; t < LT_NT; ++t) {
-        acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, cur[t], acc[t][0], 0, 0, 0);
-        acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, cur[t], acc[t][1], 0, 0, 0);
-        if (ks + 1 < 4) cur[t] = *(const bf16v8*)(base + 16 * t * LT_ROWB + 16 * (ks + 1));
-      }
-      ring[2 * ks] = *(const bf16v8*)(wnext + ks * LT_KSTEP_BYTES);
-      ring[2 * ks + 1] = *(const bf16v8*)(wnext + ks * LT_KSTEP_BYTES + LT_SUB_BYTES);
-#pragma unroll
-      for (int t = 0; t < LT_NT; ++t) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-        if (ks + 1 < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      }
-      __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+    for (int t = 0; t < LT_NT; ++t) {
+      cura[t] = addr_of(t, (a.first_tap - center) * a.dil);
+      cur[t] = *(const bf16v8*)(smem + cura[t]);
     }
-    if (more) {
-      park(buf ^ 1);       // the other buffer: its readers finished before the previous barrier
-      __syncthreads();
+    for (int tap = a.first_tap; tap <= last_tap; ++tap) {
+      const int ntap = tap < last_tap ? tap + 1 : tap;    // (after the last tap the refills are unused)
+      const char* wnext = wlane + (long)ntap * LT_TAP_BYTES;
+      int nxta[LT_NT];
+#pragma unroll
+      for (int t = 0; t < LT_NT; ++t) nxta[t] = addr_of(t, (ntap - center) * a.dil);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16v8 a0 = ring[2 * ks], a1 = ring[2 * ks + 1];
+#pragma unroll
+        for (int t = 0; t < LT_NT; ++t) {
+          acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, cur[t], acc[t][0], 0, 0, 0);
+          acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, cur[t], acc[t][1], 0, 0, 0);
+          cur[t] = ks + 1 < 4 ? *(const bf16v8*)(smem + cura[t] + 16 * (ks + 1)) : *(const bf16v8*)(smem + nxta[t]);
+        }
+        ring[2 * ks] = *(const bf16v8*)(wnext + ks * LT_KSTEP_BYTES);
+        ring[2 * ks + 1] = *(const bf16v8*)(wnext + ks * LT_KSTEP_BYTES + LT_SUB_BYTES);
+#pragma unroll
+        for (int t = 0; t < LT_NT; ++t) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+      }
+#pragma unroll
+      for (int t = 0; t < LT_NT; ++t) cura[t] = nxta[t];
+    }
+  } else {
+    int spos[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) spos[i] = (int)((p0 + srow + 16 * i) % (unsigned)L);
+    auto fetch = [&](int off) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const long row = r0 + srow + 16 * i;
+        const int p = spos[i] + off;
+        stage[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (row < a.M && p >= 0 && p < L) stage[i] = *(const f32x4*)(a.h + (row + off) * 256 + 16 * scol);
+      }
+    };
+    auto park = [&](int buf) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) *(f32x4*)(tile0 + buf * (LT_ROWS * LT_ROWB) + (srow + 16 * i) * LT_ROWB + 16 * scol) = stage[i];
+    };
+    fetch((a.first_tap - center) * a.dil);
+    park(0);
+    __syncthreads();
+    for (int tap = a.first_tap; tap <= last_tap; ++tap) {
+      const int buf = (tap - a.first_tap) & 1;
+      const bool more = tap < last_tap;
+      if (more) fetch((tap + 1 - center) * a.dil);           // in flight under this tap's MFMAs
+      const char* wnext = wlane + (long)(more ? tap + 1 : tap) * LT_TAP_BYTES;   // (after the last tap the refill is unused)
+      const char* base = tile0 + buf * (LT_ROWS * LT_ROWB) + pn * LT_ROWB + goff;
+      bf16v8 cur[LT_NT];
+#pragma unroll
+      for (int t = 0; t < LT_NT; ++t) cur[t] = *(const bf16v8*)(base + 16 * t * LT_ROWB);
+      __builtin_amdgcn_sched_group_barrier(0x100, LT_NT, 0);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16v8 a0 = ring[2 * ks], a1 = ring[2 * ks + 1];
+#pragma unroll
+        for (int t = 0; t < LT_NT; ++t) {
+          acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, cur[t], acc[t][0], 0, 0, 0);
+          acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, cur[t], acc[t][1], 0, 0, 0);
+          if (ks + 1 < 4) cur[t] = *(const bf16v8*)(base + 16 * t * LT_ROWB + 16 * (ks + 1));
+        }
+        ring[2 * ks] = *(const bf16v8*)(wnext + ks * LT_KSTEP_BYTES);
+        ring[2 * ks + 1] = *(const bf16v8*)(wnext + ks * LT_KSTEP_BYTES + LT_SUB_BYTES);
+#pragma unroll
+        for (int t = 0; t < LT_NT; ++t) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          if (ks + 1 < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+      }
+      if (more) {
+        park(buf ^ 1);       // the other buffer: its readers finished before the previous barrier
+        __syncthreads();
+      }
     }
   }
 
   // ---- epilogue ---------------------------------------------------------------------------------------------------
   {
 #pragma clang fp contract(fast)
-  const int ch0 = 32 * ct + 4 * g;
   const f32x4 cb0 = *(const f32x4*)(a.bias + ch0), cb1 = *(const f32x4*)(a.bias + ch0 + 16);
   f32x4 x[LT_NT][2];
 #pragma unroll
@@ -142,7 +230,11 @@ __global__ void __launch_bounds__(256, 2) k_layer_bf16(const LayerArgs a) {
       f32x4 r;
 #pragma unroll
       for (int i = 0; i < 4; ++i) r[i] = fmaxf(acc[t][s][i] + cb[i], 0.f);
-      if (a.feat && ok) r += *(const f32x4*)(a.feat + row * DRK_C + ch0 + 16 * s);
+      if constexpr (PRE) {
+        r += res[t][s];
+      } else {
+        if (a.feat && ok) r += *(const f32x4*)(a.feat + row * DRK_C + ch0 + 16 * s);
+      }
       if (ok) *(f32x4*)(a.feat_out + row * DRK_C + ch0 + 16 * s) = r;
       x[t][s] = r;
     }
@@ -200,7 +292,7 @@ __global__ void __launch_bounds__(256, 2) k_layer_bf16(const LayerArgs a) {
   // h' tile -> LDS (natural channel order), then out as whole rows
 #pragma unroll
   for (int t = 0; t < LT_NT; ++t) {
-    char* row = &tile[0][(16 * t + pn) * LT_ROWB + 2 * ch0];
+    char* row = tile0 + (16 * t + pn) * LT_ROWB + 2 * ch0;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       bf16v4 pk;
@@ -212,7 +304,7 @@ __global__ void __launch_bounds__(256, 2) k_layer_bf16(const LayerArgs a) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const long row = r0 + srow + 16 * i;
-    if (row < a.M) *(f32x4*)(a.h_out + row * 256 + 16 * scol) = *(const f32x4*)(&tile[0][(srow + 16 * i) * LT_ROWB + 16 * scol]);
+    if (row < a.M) *(f32x4*)(a.h_out + row * 256 + 16 * scol) = *(const f32x4*)(tile0 + (srow + 16 * i) * LT_ROWB + 16 * scol);
   }
   }
 }
@@ -261,7 +353,13 @@ extern "C" int drk_layer_bf16(const void* h, const float* feat, float* feat_out,
   int reach = center;
   if (dilation > 0 && (L - 1) / dilation < reach) reach = (L - 1) / dilation;
   a.first_tap = center - reach;
-  hipLaunchKernelGGL(k_layer_bf16, dim3((unsigned)((a.M + LT_ROWS - 1) / LT_ROWS)), dim3(256), 0, (hipStream_t)stream, a);
+  const dim3 grid((unsigned)((a.M + LT_ROWS - 1) / LT_ROWS));
+  const int rows_total = LT_ROWS + 2 * center * dilation;
+  // (a 160-row, three-workgroups-per-CU variant for dilation <= 4 measured the same: the launch is HBM-bound)
+  if (rows_total <= 256)             // rows + halo fetched once, residual prefetched
+    hipLaunchKernelGGL((k_layer_bf16<true, 256, 2, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  else                               // one fetch per tap
+    hipLaunchKernelGGL((k_layer_bf16<false, 256, 2, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
   DRK_CHECK_LAUNCH();
   return DRK_OK;
 }
