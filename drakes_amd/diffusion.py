@@ -236,6 +236,10 @@ class Diffusion(nn.Module):
         table, _, _, _ = noise_schedule.step_table(self.noise, num_steps, eps)
         table = table.tolist()
         bb = self.backbone
+        fwd = bb.forward_f32
+        if self.hip_dtype == 'bf16':       # batched forwards on the bf16 layer kernels (logits within the bf16 bar)
+            from . import fastpath
+            fwd = lambda seq, tb, stride, work: fastpath.forward_bf16_layers(bb, seq, tb, stride, work)
         shared = None if self.time_conditioning else self._shared_time_bias(0.0)
         total = torch.zeros(B, dtype=torch.float32, device=x0.device)
         acc = torch.empty(B, L, dtype=torch.float32, device=x0.device)
@@ -250,7 +254,7 @@ class Diffusion(nn.Module):
                 u = uniforms(s, i) if uniforms is not None else None
                 ops.q_xt(x0, mc_t, seed + s, i, sample_offset, u, out=xt)
                 tb = shared if shared is not None else self._shared_time_bias(sigma_t)
-                logits = bb.forward_f32(xt, tb, 0, self._work)
+                logits = fwd(xt, tb, 0, self._work)
                 ops.likelihood_accum(logits, x0, xt, mult, acc)
             total += acc.sum(dim=-1)
         return total / n_samples

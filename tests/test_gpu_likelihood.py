@@ -30,3 +30,9 @@ def test_get_likelihood_golden(dev, det_sd, tag, tc):
     ll = m.get_likelihood(x0, n_samples=int(g['n_samples']), seed=int(g['useed'])).cpu().numpy()
     print(ll, g['loglik' + tag])
     np.testing.assert_allclose(ll, g['loglik' + tag], rtol=2e-5)
+    # hip_dtype = 'bf16': the same loop with the denoiser on the bf16 layer kernels.  Floating-point bar: logits within
+    # 6e-2 / 1e-2 rms of fp32 (tests/test_gpu_bf16.py), which leaves the summed log-likelihood within 1e-3 relative.
+    m.hip_dtype = 'bf16'
+    ll16 = m.get_likelihood(x0, n_samples=int(g['n_samples']), seed=int(g['useed'])).cpu().numpy()
+    print('bf16:', ll16)
+    np.testing.assert_allclose(ll16, g['loglik' + tag], rtol=1e-3)
