@@ -19,6 +19,25 @@ def _zeros(*shape, like):
     return torch.zeros(*shape, dtype=torch.float32, device=like.device)
 
 
+class _ZeroPool:
+    """ONE zero-filled fp32 buffer per backward call, carved into the ~90 gradient accumulators the kernels add into
+    (one fill launch instead of one per accumulator; pieces start on 16-byte boundaries)."""
+
+    def __init__(self, numel, like):
+        self.buf = torch.zeros(numel, dtype=torch.float32, device=like.device)
+        self.off = 0
+
+    def __call__(self, *shape):
+        n = 1
+        for d in shape:
+            n *= d
+        if self.off + n > self.buf.numel():          # never on the sized paths; keeps the pool safe under changes
+            return torch.zeros(*shape, dtype=torch.float32, device=self.buf.device)
+        v = self.buf[self.off:self.off + n].view(*shape)
+        self.off += (n + 3) // 4 * 4
+        return v
+
+
 class _BackboneFn(torch.autograd.Function):
     """logits = CNNModel(seq, sigma).  sigma has one element per batch row, or ONE element shared by
     the whole batch (the sampler's case: all rows sit at the same time, :527-528)."""
@@ -63,20 +82,21 @@ class _BackboneFn(torch.autograd.Function):
         dlogits = dlogits.contiguous()
         g = {}
         want_w = any(ctx.needs_input_grad[3:])     # a frozen model (the KL reference model) only passes the input gradient on
+        zeros = _ZeroPool((n * 9 * C * C if want_w else 0) + n * nb * C + (n + 2) * C * C + 16 * V * C + (6 * n + 16) * C, dlogits)
         # head
         dy = torch.empty_like(y)
-        dw2, db2 = _zeros(V, C, like=y), _zeros(V, like=y)
+        dw2, db2 = zeros(V, C), zeros(V)
         ops.head_out_bwd(dlogits, y, pk['head2_w'], dy, dw2, db2)
         dpre = ops.relu_bwd(dy, y, out=dy)
-        dw0 = _zeros(1, C, C, like=y)
-        db0 = _zeros(1, C, like=y)
+        dw0 = zeros(1, C, C)
+        db0 = zeros(1, C)
         if want_w:
             ops.conv_wgrad_f32(feats[n], dpre, dw0, 0, db0[0])
         gr = ops.conv_fwd_f32(dpre, pk['head0_wT'], None, None, 0, relu=False)
         g['final_conv.2.weight'], g['final_conv.2.bias'] = dw2.unsqueeze(-1), db2
         g['final_conv.0.weight'], g['final_conv.0.bias'] = dw0.permute(2, 1, 0), db0[0]
         # layers
-        dtb = _zeros(n, nb, C, like=y)
+        dtb = zeros(n, nb, C)
         h = torch.empty_like(y)
         dc = torch.empty_like(y)
         dh = torch.empty_like(y)
@@ -86,11 +106,11 @@ class _BackboneFn(torch.autograd.Function):
             ops.mask_mul(gr, masks[i], out=dc)
             if want_w:
                 ops.ln_fwd(feats[i], ctx.tbias[0, i], ctx.tb_stride, pk['ln_g'][i], pk['ln_b'][i], out=h)
-                dwt, dbias = _zeros(9, C, C, like=y), _zeros(C, like=y)
+                dwt, dbias = zeros(9, C, C), zeros(C)
                 ops.conv_wgrad_f32(h, dc, dwt, d, dbias)          # the bias gradient rides on the centre tap
                 g[f'convs.{i}.weight'], g[f'convs.{i}.bias'] = dwt.permute(2, 1, 0), dbias
             ops.conv_fwd_f32(dc, pk['conv_wT'][i], None, None, d, relu=False, out=dh)
-            dgam, dbet = _zeros(C, like=y), _zeros(C, like=y)
+            dgam, dbet = zeros(C), zeros(C)
             gnew = torch.empty_like(y)
             shared_tb = want_w and not ctx.tb_stride          # one time-bias row for the batch: its gradient is fused in
             ops.ln_bwd(dh, feats[i], ctx.tbias[0, i], ctx.tb_stride, pk['ln_g'][i], means[i], rstds[i], gr, dxin, gnew,
@@ -102,16 +122,16 @@ class _BackboneFn(torch.autograd.Function):
         # stem
         dpre = ops.relu_bwd(gr, feats[0], out=gr)
         if want_w:
-            g['linear.bias'] = ops.colsum128(dpre, 1, M, _zeros(1, C, like=y))[0]
-        dw_t = _zeros(9, V, C, like=y)
+            g['linear.bias'] = ops.colsum128(dpre, 1, M, zeros(1, C))[0]
+        dw_t = zeros(9, V, C)
         dseq = None
         if seq.dtype != torch.int64:
             dseq = torch.empty_like(seq)
         ops.stem_bwd(dpre, seq, pk['stem_w'], dw_t, dseq)
         g['linear.weight'] = dw_t.permute(2, 1, 0)
         # time path
-        d_dense_w, d_dense_b = _zeros(n, C, C, like=y), _zeros(n, C, like=y)
-        d_lin_w, d_lin_b = _zeros(C, C, like=y), _zeros(C, like=y)
+        d_dense_w, d_dense_b = zeros(n, C, C), zeros(n, C)
+        d_lin_w, d_lin_b = zeros(C, C), zeros(C)
         if want_w:
             ops.time_bwd(dtb.permute(1, 0, 2).contiguous(), ctx.sigma, pk['four_W'], ctx.temb, pk['dense_w'], d_dense_w,
                          d_dense_b, d_lin_w, d_lin_b)

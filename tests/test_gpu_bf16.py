@@ -222,3 +222,22 @@ def test_long_sequences_take_the_layer_path(dev, det_sd):
     m.hip_graph = False
     with pytest.raises(NotImplementedError):
         fastpath.sample_bf16(m, torch.full((1, 1024), 4, dtype=torch.int64, device=dev), [], 0.0, 0, 0, None)
+
+
+def test_fused_full_size_properties(dev, det_sd):
+    """BASELINE.json configs[1] at full size (B = 1024, L = 200, 128 steps + noise removal), where the oracle is too slow
+    to be the checker: size-independent properties.  Same seed -> same tokens; rows 512.. of the full batch equal a
+    512-row call at sample_offset = 512 (what bench.py's ranks rely on); every token is a nucleotide; another seed
+    gives another sample."""
+    m = drakes_amd.Diffusion(drakes_amd.default_config()).to(dev)
+    m.load_state_dict(det_sd)
+    m.hip_dtype = 'bf16'
+    a = m._sample(eval_sp_size=1024, seed=123)
+    b = m._sample(eval_sp_size=1024, seed=123)
+    half = m._sample(eval_sp_size=512, seed=123, sample_offset=512)
+    c = m._sample(eval_sp_size=1024, seed=124)
+    assert a.shape == (1024, 200) and a.dtype == torch.int64
+    assert torch.equal(a, b)
+    assert torch.equal(a[512:], half)
+    assert int(a.min()) >= 0 and int(a.max()) <= 3
+    assert (a != c).float().mean().item() > 0.5
