@@ -19,7 +19,7 @@
 //     this shape than on 32x32x16 (MI355X_MICROARCH.md, DVFS item 7).  The accumulator holds, per lane,
 //     ONE position and 4 channels per 16x16 tile, which makes the LayerNorm reduction a local sum,
 //     two cross-lane swaps and four partials through LDS, and the h write-back 8-byte stores;
-//   * stem (a 9-row gather-add from an LDS-resident table), final_conv.0/.2, SUBS, posterior, Philox,
+//   * stem (an MFMA over K = 9 taps x 8 one-hot slots, the one-hot built in registers), final_conv.0/.2, SUBS, posterior, Philox,
 //     Gumbel-argmax and carry-over are fused in; per step only the tokens change, and they stay in LDS;
 //     biases, LayerNorm affine terms and time biases of all layers are LDS-resident.
 // HBM traffic per sequence per step: ~0 (tokens out once at the end).  MFMA-bound.
@@ -44,6 +44,7 @@
 typedef __bf16 bf16v8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16v4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 #define ROWB 272                 // bytes per h-image row: 128 bf16 + 16 B pad (bank slot = (row + chunk) mod 16); a
                                  // k-step is an IMMEDIATE offset (+16 B) from a per-lane row address: no address VALU
@@ -52,23 +53,22 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 #define TAP_BYTES 32768          // one tap of one layer in the fragment stream: [4 k-steps][4 ct][2 s][64 lanes][16 B]
 #define KSTEP_BYTES 8192
 #define SUB_BYTES 1024
-#define STEM_ROWS 46             // resident stem table: row 5*tap + v = the 128 output channels (bf16); row 45 = zeros
-#define STEM_ROWB 272
+#define STEM_BYTES 24576         // resident stem weights as MFMA A fragments: [3 k-steps][4 ct][2 s][64 lanes][16 B]
 #define HEAD2_ROWB 272           // final_conv.2: [8 rows][128] bf16, rows 5..7 zero
 #define MAX_LAYERS 20
 #define OFF_HB 0
 #define OFF_STEM (OFF_HB + (ZROW + 1) * ROWB)       // 61200
-#define OFF_HEAD2 (OFF_STEM + STEM_ROWS * STEM_ROWB)
+#define OFF_HEAD2 (OFF_STEM + STEM_BYTES)
 #define OFF_PART (OFF_HEAD2 + 8 * HEAD2_ROWB)       // float [2][4][224]: per channel-tile sum, sum of squares
 #define OFF_LOG (OFF_PART + 2 * 4 * MAXPOS * 4)     // float [224][8]
 #define OFF_TOK (OFF_LOG + MAXPOS * 8 * 4)          // int [224]
 #define OFF_VECS (OFF_TOK + MAXPOS * 4)             // float [n_layers+1][3][128]
 #define OFF_TB (OFF_VECS + (MAX_LAYERS + 1) * 3 * 128 * 4)   // float [n_layers][128]
-#define LDS_BYTES (OFF_TB + MAX_LAYERS * 128 * 4)   // 133 744 of 163 840
+#define LDS_BYTES (OFF_TB + MAX_LAYERS * 128 * 4)   // 145 808 of 163 840
 
 struct SampleArgs {
   const char* wfrag;        // conv weights in fragment order: n_layers*9 taps, then final_conv.0 (fastpath.py)
-  const char* stem_w;       // [46][128] bf16: row 5*tap + v, row 45 zero
+  const char* stem_w;       // stem weights in fragment order, K = 8*tap + v padded to 96: [3][4][2][64][8] bf16 (fastpath.py)
   const char* head2_w;      // [8][128] bf16, rows 5..7 zero
   const float* vecs;        // [n_layers+1] blocks of [3][128]: block 0 = stem bias, gamma_0, beta_0; block k+1 =
                             // conv bias_k, gamma_{k+1}, beta_{k+1}; the last block = conv bias_{n-1}, head0 bias, head2 bias
@@ -458,8 +458,7 @@ __device__ __forceinline__ void sample_body(const SampleArgs& a, char* smem, int
   // ---- init: tokens, zero row, resident weights and vectors, the first tap's fragments --------
   for (int i = tid; i < MAXPOS; i += NTHR) tok[i] = (i < L) ? (a.x_init ? (int)a.x_init[b * L + i] : DRK_MASK) : DRK_MASK;
   if (tid < ROWB / 4) ((int*)(smem + OFF_HB + ZROW * ROWB))[tid] = 0;   // the zero row (its pad bytes too)
-  for (int i = tid; i < STEM_ROWS * 16; i += NTHR)                       // 16 x 16 B per table row, rows padded in LDS
-    *(f32x4*)(smem + OFF_STEM + (i >> 4) * STEM_ROWB + (i & 15) * 16) = ((const f32x4*)a.stem_w)[i];
+  for (int i = tid; i < STEM_BYTES / 16; i += NTHR) ((f32x4*)(smem + OFF_STEM))[i] = ((const f32x4*)a.stem_w)[i];
   if (tid < 8 * 16) *(f32x4*)(smem + OFF_HEAD2 + (tid >> 4) * HEAD2_ROWB + (tid & 15) * 16) = ((const f32x4*)a.head2_w)[tid];
   for (int i = tid; i < (a.n_layers + 1) * 3 * 128 / 4; i += NTHR) ((f32x4*)(smem + OFF_VECS))[i] = ((const f32x4*)a.vecs)[i];
   // The ring always holds the weight fragments of the tap about to run and is refilled, k-step by k-step, with those
@@ -482,28 +481,42 @@ __device__ __forceinline__ void sample_body(const SampleArgs& a, char* smem, int
       for (int i = tid; i < a.n_layers * 128 / 4; i += NTHR) ((f32x4*)(smem + OFF_TB))[i] = ((const f32x4*)tb)[i];
     }
 
-    // ---- stem: Conv1d(5 -> 128, k = 9) of a one-hot input = the sum of 9 table rows -------------
+    // ---- stem: Conv1d(5 -> 128, k = 9) of a one-hot input as an MFMA with K = 8*tap + v (72, padded to 96) --------
+    // B operand = the one-hot itself, built in registers: in k-step ks lane group g holds the 8 slots of tap 4ks + g,
+    // i.e. bf16 1.0 in slot tok[p + tap - 4] (nothing for a padding position or tap > 8); A = LDS-resident fragments.
     __syncthreads();   // tokens / resident tables written above are visible
     if (a.traj_out && tid < L) a.traj_out[((long)f * a.B + b) * L + tid] = (signed char)tok[tid];
     {
       const int lo_s = opaque(lane);
+      const int g_s = lo_s >> 4;
       const int pn_s = (lo_s & 15) ^ ((lo_s & 8) >> 1);
-      const char* sbase = smem + OFF_STEM + 2 * (32 * ct + 4 * (lo_s >> 4));
+      const char* sfrag = smem + OFF_STEM + ct * (2 * SUB_BYTES) + lo_s * 16;
+      bf16v8 sw[3][2];
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) {
+        sw[ks][0] = *(const bf16v8*)(sfrag + ks * KSTEP_BYTES);
+        sw[ks][1] = *(const bf16v8*)(sfrag + ks * KSTEP_BYTES + SUB_BYTES);
+      }
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const int p = 16 * (grp + 2 * t) + pn_s;
         f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int k = 0; k < 9; ++k) {
-          const int q = p + k - 4;
-          const int row = ((unsigned)q < (unsigned)L) ? 5 * k + tok[q] : 45;
-          const bf16v4 w0 = *(const bf16v4*)(sbase + row * STEM_ROWB);
-          const bf16v4 w1 = *(const bf16v4*)(sbase + row * STEM_ROWB + 32);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            s0[i] += (float)w0[i];
-            s1[i] += (float)w1[i];
-          }
+        for (int ks = 0; ks < 3; ++ks) {
+          const int tapi = 4 * ks + g_s;
+          const int q = p + tapi - 4;
+          const bool live = (tapi < DRK_TAPS) && ((unsigned)q < (unsigned)L);
+          const int v = live ? tok[live ? q : 0] : 8;
+          const unsigned one = 0x3F80u << ((v & 1) << 4);   // bf16 1.0 in the low or the high half of a dword
+          const int j = v >> 1;
+          u32x4 oh;
+          oh[0] = (j == 0) ? one : 0u;
+          oh[1] = (j == 1) ? one : 0u;
+          oh[2] = (j == 2) ? one : 0u;
+          oh[3] = 0u;
+          const bf16v8 bv = __builtin_bit_cast(bf16v8, oh);
+          s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sw[ks][0], bv, s0, 0, 0, 0);
+          s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sw[ks][1], bv, s1, 0, 0, 0);
         }
         acc[t][0] = s0;
         acc[t][1] = s1;

@@ -4,8 +4,8 @@ loop, drakes_amd/csrc/drk_sample_bf16.hip) and launches it.
 Weight stream layout (MFMA-fragment order, read straight from L2 into registers):
     tap = [4 k-steps][4 co tiles][2 row tiles][64 lanes][8 bf16] = 32 KB (see _frag_tap);
     order = for each layer its 9 taps, then final_conv.0.
-The stem (a [46][128] bf16 gather table, row 5*tap+v) and final_conv.2 ([8][128] bf16, rows 0..4) are small
-and stay resident in LDS for the whole launch.
+The stem (MFMA A fragments over K = 8*tap + v padded to 96: [3 k-steps][4 co tiles][2 row tiles][64 lanes][8], see
+_frag_stem) and final_conv.2 ([8][128] bf16, rows 0..4) are small and stay resident in LDS for the whole launch.
 """
 import ctypes
 
@@ -24,15 +24,22 @@ def _frag_tap(m):
     return w.permute(5, 0, 1, 4, 3, 2, 6).contiguous().reshape(4, 4, 2, 64, 8)
 
 
+def _frag_stem(w):
+    """linear.weight [128 co][5 v][9 taps] -> bf16 [3 k-steps][4 co tiles][2 row tiles][64 lanes][8]: the stem as a
+    GEMM over K = 8*tap + v (v = 5..7 and taps 9..11 zero).  Lane 16g + n holds, for k-step ks and row tile s,
+    W[32ct + 16s + n][v = 0..7][tap = 4ks + g]; the kernel builds the matching one-hot B operand in registers."""
+    wk = torch.zeros(128, 12, 8, device=w.device)
+    wk[:, :9, :5] = w.permute(0, 2, 1)
+    wk = wk.to(torch.bfloat16).reshape(4, 2, 16, 3, 4, 8)      # [ct][s][n][ks][g][j]
+    return wk.permute(3, 0, 1, 4, 2, 5).contiguous().reshape(3, 4, 2, 64, 8)
+
+
 def pack_stream(bb):
     """bb: models.dnaconv.CNNModel -> dict of device tensors the fused kernel reads."""
     dev = bb.linear.weight.device
     n = bb.num_layers
     with torch.no_grad():
         stages = []
-        stem = torch.zeros(46, 128, device=dev)
-        # linear.weight [co][v][tap] -> row 5*tap + v of a gather table (LDS-resident); row 45 stays zero
-        stem[:45] = bb.linear.weight.permute(2, 1, 0).reshape(45, 128)
         for i in range(n):
             w = bb.convs[i].weight          # [co][ci][tap]
             for t in range(9):
@@ -52,7 +59,7 @@ def pack_stream(bb):
                 vec_rows += [bb.convs[k].bias, bb.final_conv[0].bias, hb2]
         return {
             'wstream': torch.stack(stages).contiguous(),
-            'stem_w': stem.to(torch.bfloat16).contiguous(),
+            'stem_w': _frag_stem(bb.linear.weight.detach()),
             'head2_w': head2[:8].to(torch.bfloat16).contiguous(),
             'vecs': torch.stack([v.detach().float() for v in vec_rows]).contiguous(),
             'dil': (ctypes.c_int * n)(*[bb.dilation(i) for i in range(n)]),

@@ -206,7 +206,7 @@ int drk_kl_step_bwd(const float* logp, const float* logp_old, const float* last_
  * num_steps x (CNNModel.forward + _subs_parameterization + _ddpm_update tail) and, if
  * noise_removal, the final forward + argmax (:541-549).  One workgroup per sequence; L <= 224.
  *   wstream   bf16 weight stages: n_layers*9 conv taps + final_conv.0 (layout: drakes_amd/fastpath.py::pack_stream)
- *   stem_w    bf16 [46][128] stem gather table (row 5*tap + v, row 45 zero), head2_w bf16 [8][128] final_conv.2 weights (same file)
+ *   stem_w    bf16 [3][4][2][64][8] stem weights as MFMA fragments over K = 8*tap + v (fastpath.py::_frag_stem), head2_w bf16 [8][128] final_conv.2 weights (same file)
  *   vecs      float32 [n_layers+1][3][128] biases and LayerNorm affine terms (same file)
  *   tbias     float32 [n_tb][n_layers][128] time biases (drk_time_bias_fwd); forward f reads row
  *             f * tb_fwd_stride / (n_layers*128) (stride 0: time_conditioning=False)
