@@ -59,12 +59,14 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define OFF_HB 0
 #define OFF_STEM (OFF_HB + (ZROW + 1) * ROWB)       // 61200
 #define OFF_HEAD2 (OFF_STEM + STEM_BYTES)
-#define OFF_PART (OFF_HEAD2 + 8 * HEAD2_ROWB)       // float [2][4][224]: per channel-tile sum, sum of squares
-#define OFF_LOG (OFF_PART + 2 * 4 * MAXPOS * 4)     // float [224][8]
+#define PART_STRIDE 12                              // floats per position in the LayerNorm partial buffer (8 used): 48-byte
+                                                    // rows make the two ds_read_b128 of a position conflict-free
+#define OFF_PART (OFF_HEAD2 + 8 * HEAD2_ROWB)       // float [224][12]: slots 0-3 = per channel-tile sum, 4-7 = sum of squares
+#define OFF_LOG (OFF_PART + MAXPOS * PART_STRIDE * 4)   // float [224][8]
 #define OFF_TOK (OFF_LOG + MAXPOS * 8 * 4)          // int [224]
 #define OFF_VECS (OFF_TOK + MAXPOS * 4)             // float [n_layers+1][3][128]
 #define OFF_TB (OFF_VECS + (MAX_LAYERS + 1) * 3 * 128 * 4)   // float [n_layers][128]
-#define LDS_BYTES (OFF_TB + MAX_LAYERS * 128 * 4)   // 145 808 of 163 840
+#define LDS_BYTES (OFF_TB + MAX_LAYERS * 128 * 4)   // 149 392 of 163 840
 
 struct SampleArgs {
   const char* wfrag;        // conv weights in fragment order: n_layers*9 taps, then final_conv.0 (fastpath.py)
@@ -356,14 +358,14 @@ __device__ __forceinline__ void epilogue_ln(char* smem, f32x4 (&feat)[NT][2], co
     // lower half-wave: s1(lower) + s1(upper); upper half-wave: s2(lower) + s2(upper)
     y[t] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
   }
-  const int stat_ct = ((g >> 1) * 4 + ct) * MAXPOS;
+  const int stat_ct = (g >> 1) * 4 + ct;
 #pragma unroll
   for (int t = 0; t < NT; t += 2) {
     const int tb = (t + 1 < NT) ? t + 1 : t;   // odd count: the last tile pairs with itself
     const u32x2 sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(y[t]), __float_as_uint(y[tb]), false, false);
     // rows 0,2 (g even): tile t; rows 1,3 (g odd): tile tb
     const int tile = (g & 1) ? tb : t;
-    part[stat_ct + 16 * (grp + 2 * tile) + pn] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    part[(16 * (grp + 2 * tile) + pn) * PART_STRIDE + stat_ct] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
   }
   f32x4 gv[2], bv[2];
   load_vec8(blk + 128, ch0, gv);
@@ -372,8 +374,9 @@ __device__ __forceinline__ void epilogue_ln(char* smem, f32x4 (&feat)[NT][2], co
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int p = 16 * (grp + 2 * t) + pn;
-    const float s1 = (part[0 * MAXPOS + p] + part[1 * MAXPOS + p]) + (part[2 * MAXPOS + p] + part[3 * MAXPOS + p]);
-    const float s2 = (part[4 * MAXPOS + p] + part[5 * MAXPOS + p]) + (part[6 * MAXPOS + p] + part[7 * MAXPOS + p]);
+    const f32x4 q1 = *(const f32x4*)(part + p * PART_STRIDE), q2 = *(const f32x4*)(part + p * PART_STRIDE + 4);
+    const float s1 = (q1[0] + q1[1]) + (q1[2] + q1[3]);
+    const float s2 = (q2[0] + q2[1]) + (q2[2] + q2[3]);
     const float mean = s1 * (1.0f / 128.0f);
     const float var = fmaxf(s2 * (1.0f / 128.0f) - mean * mean, 0.0f);
     const float rstd = __builtin_amdgcn_rsqf(var + 1e-5f);

@@ -94,6 +94,19 @@ def test_weight_packing_is_a_permutation():
     assert ops.pack_stem_weight(ws)[8, 4, 100] == ws[100, 4, 8]
 
 
+def test_fused_sampler_stem_fragments():
+    """fastpath._frag_stem: lane 16g + n of co tile ct, row tile s, k-step ks holds W[32ct+16s+n][v=j][tap=4ks+g]."""
+    from drakes_amd import fastpath
+    ws = (torch.arange(128 * 5 * 9, dtype=torch.float32).reshape(128, 5, 9) % 251) - 125   # exact in bf16
+    fr = fastpath._frag_stem(ws).float()
+    assert fr.shape == (3, 4, 2, 64, 8)
+    for ks, ct, s, g, n, j in [(0, 0, 0, 0, 0, 0), (1, 3, 1, 2, 9, 4), (2, 1, 0, 0, 15, 3), (0, 2, 1, 3, 7, 1)]:
+        assert fr[ks, ct, s, 16 * g + n, j] == ws[32 * ct + 16 * s + n, j, 4 * ks + g]
+    assert float(fr[:, :, :, :, 5:].abs().max()) == 0            # one-hot slots 5..7 do not exist
+    assert float(fr[2, :, :, 16:, :].abs().max()) == 0           # taps 9..11 do not exist
+    assert fr.abs().sum() == ws.abs().sum()                      # nothing lost, nothing duplicated
+
+
 def test_sample_prior_and_sigma_processing():
     m = drakes_amd.Diffusion(drakes_amd.default_config())
     x = m._sample_prior(3, 200)
