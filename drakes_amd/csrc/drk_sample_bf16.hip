@@ -56,8 +56,9 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define STEM_BYTES 24576         // resident stem weights as MFMA A fragments: [3 k-steps][4 ct][2 s][64 lanes][16 B]
 #define HEAD2_ROWB 272           // final_conv.2: [8 rows][128] bf16, rows 5..7 zero
 #define MAX_LAYERS 20
-#define OFF_HB 0
-#define OFF_STEM (OFF_HB + (ZROW + 1) * ROWB)       // 61200
+#define HPAD 16                  // all-zero rows in front of the h image (logical rows -16..-1); rows L..223 stay zero too
+#define OFF_HB (HPAD * ROWB)     // logical row 0
+#define OFF_STEM (OFF_HB + (ZROW + 1) * ROWB)       // 65552
 #define OFF_HEAD2 (OFF_STEM + STEM_BYTES)
 #define PART_STRIDE 12                              // floats per position in the LayerNorm partial buffer (8 used): 48-byte
                                                     // rows make the two ds_read_b128 of a position conflict-free
@@ -66,7 +67,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define OFF_TOK (OFF_LOG + MAXPOS * 8 * 4)          // int [224]
 #define OFF_VECS (OFF_TOK + MAXPOS * 4)             // float [n_layers+1][3][128]
 #define OFF_TB (OFF_VECS + (MAX_LAYERS + 1) * 3 * 128 * 4)   // float [n_layers][128]
-#define LDS_BYTES (OFF_TB + MAX_LAYERS * 128 * 4)   // 149 392 of 163 840
+#define LDS_BYTES (OFF_TB + MAX_LAYERS * 128 * 4)   // 153 744 of 163 840
 
 struct SampleArgs {
   const char* wfrag;        // conv weights in fragment order: n_layers*9 taps, then final_conv.0 (fastpath.py)
@@ -166,12 +167,54 @@ __device__ __forceinline__ void mma_tap(const char* smem, const char* __restrict
   }
 }
 
+// ---- immediate addressing --------------------------------------------------------------------------------------
+// The h image is physically zero-padded: HPAD all-zero rows in front of it, and rows L..223 are never written.  A shifted
+// read that leaves [0, L) by at most HPAD rows then lands on zeros by itself, and the address of (tile t, shift off,
+// k-step ks) is ONE per-lane base register plus the compile-time constant RI(grp, t, off) + 16 ks, which fits the 16-bit
+// offset field of ds_read_b128: no per-tile address arithmetic, compare or select in the tap loops (they are bound by
+// the SIMD's vector issue: every VALU instruction beside the MFMAs costs MFMA slots, MI355X_MICROARCH.md "ISSUE cost").
+#define RI(grp, t, off) ((HPAD + 16 * ((grp) + 2 * (t)) + (off)) * ROWB)
+
+// This lane's base: physical row 0 (logical row -HPAD) at its position-in-tile and k-slot group.
+__device__ __forceinline__ const char* pad_base(const char* smem, int lane) {
+  const int lo = opaque(lane);
+  const int pn = (lo & 15) ^ ((lo & 8) >> 1);
+  return smem + (OFF_HB - HPAD * ROWB) + pn * ROWB + 128 * ((lo >> 4) & 1) + 64 * (lo >> 5);
+}
+
+// mma_tap for dilation <= 4 (every shift within HPAD rows): hcur / hnext = pad_base shifted by this / the next tap.
+template <int NT, int GRP, bool HAS_NEXT>
+__device__ __forceinline__ void mma_tap_pad(const char* hcur, const char* hnext, const char* __restrict__ wnext,
+                                            bf16v8 (&ring)[8], bf16v8 (&cur)[NT], f32x4 (&acc)[NT][2]) {
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const bf16v8 a0 = ring[2 * ks], a1 = ring[2 * ks + 1];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, cur[t], acc[t][0], 0, 0, 0);
+      acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, cur[t], acc[t][1], 0, 0, 0);
+      if (ks + 1 < 4)
+        cur[t] = *(const bf16v8*)(hcur + RI(GRP, t, 0) + 16 * (ks + 1));
+      else if (HAS_NEXT)
+        cur[t] = *(const bf16v8*)(hnext + RI(GRP, t, 0));
+    }
+    ring[2 * ks] = *(const bf16v8*)(wnext + ks * KSTEP_BYTES);
+    ring[2 * ks + 1] = *(const bf16v8*)(wnext + ks * KSTEP_BYTES + SUB_BYTES);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      if (ks + 1 < 4 || HAS_NEXT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+  }
+}
+
 // ---- layers with dead tiles: straight-line taps with COMPILE-TIME live ranges ------------------------------------
 // With dilation 16 and 64 many (tile, tap) pairs multiply nothing but padding: a tile whose 16 shifted rows all fall
 // outside [0, L) (53 % of the pairs at dilation 64, 17 % at 16, 12 % of a whole forward).  Skipping them under a
 // runtime test does not pay (a wave-uniform branch per tile makes the compiler drain the LDS queue at every join;
 // a switch over variants spills).  But for 192 < L <= 208 and shifts that are multiples of 16 the live tiles of every
-// tap are known at compile time: tile T (positions 16T..16T+15) is live for shift `off` iff 16T + off <= 192 (off > 0)
+// tap are known at compile time: tile T (positions 16T..16T+15) is live for shift `off` iff 16T + off < 208 (off > 0)
 // or 16T + 15 >= -off (off < 0).  The dead tiles of a wave are a prefix or a suffix of its tiles, so a tap is a static
 // range [T0, T1), and a layer is 2m+1 different instantiations in a row: no branch, no join, exact LDS-read counts.
 __host__ __device__ constexpr int live_lo(int off, int grp, int nt) {   // first live t of the wave's tiles T = grp + 2t
@@ -181,23 +224,16 @@ __host__ __device__ constexpr int live_lo(int off, int grp, int nt) {   // first
 }
 __host__ __device__ constexpr int live_hi(int off, int grp, int nt) {   // one past the last live t
   int t = nt;
-  while (t > 0 && off > 0 && 16 * (grp + 2 * (t - 1)) + off > 192) --t;
+  while (t > 0 && off > 0 && 16 * (grp + 2 * (t - 1)) + off >= 208) --t;
   return t < live_lo(off, grp, nt) ? live_lo(off, grp, nt) : t;
 }
 
-// One tap over the static tile range [T0, T1); during the last k-step the k-step-0 fragments of the NEXT tap's range
-// [N0, N1) are fetched (shift off_next).  Otherwise as mma_tap.
-template <int NT, int T0, int T1, int N0, int N1>
-__device__ __forceinline__ void mma_tap_static(const char* smem, const char* __restrict__ wnext, bf16v8 (&ring)[8],
-                                               int off_next, int L, int lane, int grp, const char* (&bp)[NT],
+// One tap (shift OFF) over the static tile range [T0, T1); during the last k-step the k-step-0 fragments of the NEXT
+// tap's range [N0, N1) are fetched (shift OFFN).  hb = pad_base: a live tile's shifted rows are rows of the image (or
+// its zero rows 200..207), so every address is hb + a constant.  Otherwise as mma_tap.
+template <int NT, int GRP, int OFF, int T0, int T1, int OFFN, int N0, int N1>
+__device__ __forceinline__ void mma_tap_static(const char* hb, const char* __restrict__ wnext, bf16v8 (&ring)[8],
                                                bf16v8 (&cur)[NT], f32x4 (&acc)[NT][2]) {
-  const int lo = opaque(lane);
-  const int pn = (lo & 15) ^ ((lo & 8) >> 1);
-  const char* hb = smem + OFF_HB + 128 * ((lo >> 4) & 1) + 64 * (lo >> 5);
-  auto next_row = [&](int t) {
-    const int pp = 16 * (grp + 2 * t) + pn + off_next;
-    return hb + (((unsigned)pp < (unsigned)L) ? pp : ZROW) * ROWB;
-  };
   if constexpr (T1 - T0 >= 1 && T1 - T0 <= 2) {
     // One or two live tiles: 2-4 MFMAs per k-step cannot cover an LDS read, so all of the tap's fragments are
     // requested up front (the k-step-0 ones are in cur[] already) and one latency is paid instead of three.
@@ -206,12 +242,10 @@ __device__ __forceinline__ void mma_tap_static(const char* smem, const char* __r
 #pragma unroll
     for (int k = 0; k < 3; ++k)
 #pragma unroll
-      for (int t = 0; t < NL; ++t) f[k][t] = *(const bf16v8*)(bp[T0 + t] + 16 * (k + 1));
+      for (int t = 0; t < NL; ++t) f[k][t] = *(const bf16v8*)(hb + RI(GRP, T0 + t, OFF) + 16 * (k + 1));
 #pragma unroll
-    for (int t = N0; t < N1; ++t) {
-      bp[t] = next_row(t);
-      if (t < T0 || t >= T1) cur[t] = *(const bf16v8*)(bp[t]);
-    }
+    for (int t = N0; t < N1; ++t)
+      if (t < T0 || t >= T1) cur[t] = *(const bf16v8*)(hb + RI(GRP, t, OFFN));
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const bf16v8 a0 = ring[2 * ks], a1 = ring[2 * ks + 1];
@@ -226,7 +260,7 @@ __device__ __forceinline__ void mma_tap_static(const char* smem, const char* __r
     }
 #pragma unroll
     for (int t = T0; t < T1; ++t)
-      if (t >= N0 && t < N1) cur[t] = *(const bf16v8*)(bp[t]);
+      if (t >= N0 && t < N1) cur[t] = *(const bf16v8*)(hb + RI(GRP, t, OFFN));
     return;
   }
 #pragma unroll
@@ -235,20 +269,16 @@ __device__ __forceinline__ void mma_tap_static(const char* smem, const char* __r
     if (ks + 1 == 4) {   // tiles that only the next tap uses
 #pragma unroll
       for (int t = N0; t < N1; ++t)
-        if (t < T0 || t >= T1) {
-          bp[t] = next_row(t);
-          cur[t] = *(const bf16v8*)(bp[t]);
-        }
+        if (t < T0 || t >= T1) cur[t] = *(const bf16v8*)(hb + RI(GRP, t, OFFN));
     }
 #pragma unroll
     for (int t = T0; t < T1; ++t) {
       acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, cur[t], acc[t][0], 0, 0, 0);
       acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, cur[t], acc[t][1], 0, 0, 0);
       if (ks + 1 < 4) {
-        cur[t] = *(const bf16v8*)(bp[t] + 16 * (ks + 1));
+        cur[t] = *(const bf16v8*)(hb + RI(GRP, t, OFF) + 16 * (ks + 1));
       } else if (t >= N0 && t < N1) {
-        bp[t] = next_row(t);
-        cur[t] = *(const bf16v8*)(bp[t]);
+        cur[t] = *(const bf16v8*)(hb + RI(GRP, t, OFFN));
       }
     }
     ring[2 * ks] = *(const bf16v8*)(wnext + ks * KSTEP_BYTES);
@@ -271,28 +301,27 @@ __device__ __forceinline__ void mma_tap_static(const char* smem, const char* __r
 // Taps K .. M of a layer with static dilation D (shift K*D), each with its own live range; wn = this lane's pointer to
 // the weights of tap K+1, wafter = to the tap that follows the layer's last.
 template <int NT, int GRP, int D, int M, int K>
-__device__ __forceinline__ void static_taps(const char* smem, const char* wn, const char* wafter, bf16v8 (&ring)[8], int L,
-                                            int lane, const char* (&bp)[NT], bf16v8 (&cur)[NT], f32x4 (&acc)[NT][2]) {
+__device__ __forceinline__ void static_taps(const char* hb, const char* wn, const char* wafter, bf16v8 (&ring)[8],
+                                            bf16v8 (&cur)[NT], f32x4 (&acc)[NT][2]) {
   constexpr int off = K * D, offn = (K + 1) * D;
   constexpr bool last = (K == M);
   constexpr int T0 = live_lo(off, GRP, NT), T1 = live_hi(off, GRP, NT);
   constexpr int N0 = last ? 0 : live_lo(offn, GRP, NT), N1 = last ? 0 : live_hi(offn, GRP, NT);
-  mma_tap_static<NT, T0, T1, N0, N1>(smem, last ? wafter : wn, ring, offn, L, lane, GRP, bp, cur, acc);
-  if constexpr (!last) static_taps<NT, GRP, D, M, K + 1>(smem, wn + TAP_BYTES, wafter, ring, L, lane, bp, cur, acc);
+  mma_tap_static<NT, GRP, off, T0, T1, offn, N0, N1>(hb, last ? wafter : wn, ring, cur, acc);
+  if constexpr (!last) static_taps<NT, GRP, D, M, K + 1>(hb, wn + TAP_BYTES, wafter, ring, cur, acc);
 }
 
 // Whole MMA phase of such a layer: first tap's fragments (the only exposed LDS latency), then the taps.
 template <int NT, int GRP, int D, int M>
-__device__ __forceinline__ void static_layer(const char* smem, const char* wn, const char* wafter, bf16v8 (&ring)[8], int L,
+__device__ __forceinline__ void static_layer(const char* smem, const char* wn, const char* wafter, bf16v8 (&ring)[8],
                                              int lane, f32x4 (&acc)[NT][2]) {
   constexpr int T0 = live_lo(-M * D, GRP, NT), T1 = live_hi(-M * D, GRP, NT);
-  const char* bp[NT];
+  const char* hb = pad_base(smem, lane);
   bf16v8 cur[NT];
-  tap_rows<NT>(smem, -M * D, L, lane, GRP, bp);
 #pragma unroll
-  for (int t = T0; t < T1; ++t) cur[t] = *(const bf16v8*)(bp[t]);
+  for (int t = T0; t < T1; ++t) cur[t] = *(const bf16v8*)(hb + RI(GRP, t, -M * D));
   if (T1 > T0) __builtin_amdgcn_sched_group_barrier(0x100, T1 - T0, 0);   // the k-step-0 reads first, as a group
-  static_taps<NT, GRP, D, M, -M>(smem, wn, wafter, ring, L, lane, bp, cur, acc);
+  static_taps<NT, GRP, D, M, -M>(hb, wn, wafter, ring, cur, acc);
 }
 
 // This lane's channels: 32 ct + 16 s + 4 g + i (s = 0,1; i = 0..3) <-> register [s][i].
@@ -431,12 +460,14 @@ __device__ __forceinline__ void dump_feat(float* __restrict__ dst, long b, int L
 
 // The body, specialised on the number of position tiles this wave owns (7 for waves 0-3, 6 or 7 for
 // waves 4-7).  Positions >= L inside a computed tile are never stored.
-template <int NT, int GRP, int NTHR>
+// FAST: 192 < L <= 208 and every dilation in {1..4, 16, 64} (checked by the entry point): every layer runs on
+// immediate addressing (zero-padded image for dilation <= 4, static live ranges for 16 and 64); the generic tap loop is
+// not even compiled in, which also keeps its address registers out of the allocation.
+template <int NT, int GRP, int NTHR, bool FAST>
 __device__ __forceinline__ void sample_body(const SampleArgs& a, char* smem, int tid, int wave, int lane) {
   const int ct = wave & 3;
   constexpr int grp = GRP;
   const int L = a.L;
-  const bool static_ok = (L > 192 && L <= 208);   // 13 tiles: the live ranges of static_layer hold
   const int ntiles = (L + 15) >> 4;
   const long b = blockIdx.x;
   const uint64_t sample = a.sample_offset + (uint64_t)b;
@@ -450,6 +481,7 @@ __device__ __forceinline__ void sample_body(const SampleArgs& a, char* smem, int
   auto dil_of = [&](int layer) { return (int)((a.dilpk[layer >> 3] >> (8 * (layer & 7))) & 255ull); };
   auto reach_of = [&](int layer) {
     const int d = dil_of(layer);
+    if (FAST) return d == 64 ? 3 : 4;
     const int m = (d > 0) ? (L - 1) / d : 4;
     return m < 4 ? m : 4;
   };
@@ -460,7 +492,8 @@ __device__ __forceinline__ void sample_body(const SampleArgs& a, char* smem, int
 
   // ---- init: tokens, zero row, resident weights and vectors, the first tap's fragments --------
   for (int i = tid; i < MAXPOS; i += NTHR) tok[i] = (i < L) ? (a.x_init ? (int)a.x_init[b * L + i] : DRK_MASK) : DRK_MASK;
-  if (tid < ROWB / 4) ((int*)(smem + OFF_HB + ZROW * ROWB))[tid] = 0;   // the zero row (its pad bytes too)
+  // the whole h image starts as zeros: its padding rows, rows L..223 and the zero row are never written afterwards
+  for (int i = tid; i < (HPAD + ZROW + 1) * ROWB / 16; i += NTHR) ((f32x4*)smem)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   for (int i = tid; i < STEM_BYTES / 16; i += NTHR) ((f32x4*)(smem + OFF_STEM))[i] = ((const f32x4*)a.stem_w)[i];
   if (tid < 8 * 16) *(f32x4*)(smem + OFF_HEAD2 + (tid >> 4) * HEAD2_ROWB + (tid & 15) * 16) = ((const f32x4*)a.head2_w)[tid];
   for (int i = tid; i < (a.n_layers + 1) * 3 * 128 / 4; i += NTHR) ((f32x4*)(smem + OFF_VECS))[i] = ((const f32x4*)a.vecs)[i];
@@ -543,17 +576,25 @@ __device__ __forceinline__ void sample_body(const SampleArgs& a, char* smem, int
       }
       const char* wn = wlane + (long)(9 * layer + 4 - m + 1) * TAP_BYTES;
       const char* wafter = wlane + (long)after * TAP_BYTES;
-      bool done = false;
-      if constexpr ((NT == 7 && GRP == 0) || (NT == 6 && GRP == 1)) {
-        if (static_ok && dil == 64) {          // m == 3
-          static_layer<NT, GRP, 64, 3>(smem, wn, wafter, ring, L, lane, acc);
-          done = true;
-        } else if (static_ok && dil == 16) {   // m == 4
-          static_layer<NT, GRP, 16, 4>(smem, wn, wafter, ring, L, lane, acc);
-          done = true;
+      if constexpr (FAST) {
+        if (dil == 64) {          // m == 3
+          static_layer<NT, GRP, 64, 3>(smem, wn, wafter, ring, lane, acc);
+        } else if (dil == 16) {   // m == 4
+          static_layer<NT, GRP, 16, 4>(smem, wn, wafter, ring, lane, acc);
+        } else {                  // dilation <= 4: every shift stays within the zero padding
+          const char* hcur = pad_base(smem, lane) - 4 * dil * ROWB;
+          const int hstep = dil * ROWB;
+          bf16v8 cur[NT];
+#pragma unroll
+          for (int t = 0; t < NT; ++t) cur[t] = *(const bf16v8*)(hcur + RI(GRP, t, 0));
+          for (int k = 0; k < 8; ++k) {
+            mma_tap_pad<NT, GRP, true>(hcur, hcur + hstep, wn, ring, cur, acc);
+            hcur += hstep;
+            wn += TAP_BYTES;
+          }
+          mma_tap_pad<NT, GRP, false>(hcur, hcur, wafter, ring, cur, acc);
         }
-      }
-      if (!done) {
+      } else {
         const char* bp[NT];
         bf16v8 cur[NT];
         int off = -m * dil;
@@ -589,7 +630,13 @@ __device__ __forceinline__ void sample_body(const SampleArgs& a, char* smem, int
     __syncthreads();
     // the taps after final_conv.0 are the first conv taps of the NEXT forward: their fragments arrive under the
     // head, the reverse step and the next stem
-    {
+    if constexpr (FAST) {
+      const char* hcur = pad_base(smem, lane);
+      bf16v8 cur[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) cur[t] = *(const bf16v8*)(hcur + RI(GRP, t, 0));
+      mma_tap_pad<NT, GRP, false>(hcur, hcur, wlane + (long)first_tap * TAP_BYTES, ring, cur, acc);
+    } else {
       const char* bp[NT];
       bf16v8 cur[NT];
       tap_begin<NT>(smem, 0, L, lane, grp, bp, cur);
@@ -696,16 +743,17 @@ __device__ __forceinline__ void sample_body(const SampleArgs& a, char* smem, int
 }
 
 // 8 waves, two per SIMD (256 registers each): wave w = channel tile (w & 3) x position tiles (w >> 2) + 2t.
+template <bool FAST>
 __global__ void __launch_bounds__(512, 2) k_sample_bf16(const SampleArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: scalar branches, SGPR tile ids
   if (wave < 4)
-    sample_body<7, 0, 512>(a, smem, tid, wave, lane);
-  else if (a.L <= 208)
-    sample_body<6, 1, 512>(a, smem, tid, wave, lane);
+    sample_body<7, 0, 512, FAST>(a, smem, tid, wave, lane);
+  else if (FAST || a.L <= 208)
+    sample_body<6, 1, 512, FAST>(a, smem, tid, wave, lane);
   else
-    sample_body<7, 1, 512>(a, smem, tid, wave, lane);
+    sample_body<7, 1, 512, false>(a, smem, tid, wave, lane);
 }
 
 // ------------------------------------------------------------------------------------ C ABI
@@ -731,11 +779,17 @@ extern "C" int drk_sample_bf16(const void* wstream, const void* stem_w, const vo
     if (dilations[i] < 0 || dilations[i] > 255) return drk_set_error_msg(DRK_EINVAL, "drk_sample_bf16: dilation out of range");
     a.dilpk[i >> 3] |= (unsigned long long)dilations[i] << (8 * (i & 7));
   }
+  bool fast = (L > 192 && L <= 208);   // the all-immediate-addressing build (see sample_body)
+  for (int i = 0; i < n_layers; ++i) fast = fast && ((dilations[i] >= 1 && dilations[i] <= 4) || dilations[i] == 16 || dilations[i] == 64);
+  const void* kern = fast ? (const void*)k_sample_bf16<true> : (const void*)k_sample_bf16<false>;
   {  // per device, cheap, and not an allocation: lets the launch ask for more than 64 KB of LDS
-    hipError_t e = hipFuncSetAttribute((const void*)k_sample_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e != hipSuccess) return drk_set_error(e, "drk_sample_bf16(hipFuncSetAttribute)");
   }
-  hipLaunchKernelGGL(k_sample_bf16, dim3(B), dim3(512), LDS_BYTES, (hipStream_t)stream, a);
+  if (fast)
+    hipLaunchKernelGGL(k_sample_bf16<true>, dim3(B), dim3(512), LDS_BYTES, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(k_sample_bf16<false>, dim3(B), dim3(512), LDS_BYTES, (hipStream_t)stream, a);
   DRK_CHECK_LAUNCH();
   return DRK_OK;
 }
