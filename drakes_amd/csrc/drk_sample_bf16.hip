@@ -316,6 +316,10 @@ template <int NT, int GRP, int D, int M>
 __device__ __forceinline__ void static_layer(const char* smem, const char* wn, const char* wafter, bf16v8 (&ring)[8],
                                              int lane, f32x4 (&acc)[NT][2]) {
   constexpr int T0 = live_lo(-M * D, GRP, NT), T1 = live_hi(-M * D, GRP, NT);
+  // taps beyond +-M must have no live tile for this wave (the caller skips them, weights included)
+  static_assert(M == 4 || (live_lo(-(M + 1) * D, GRP, NT) >= live_hi(-(M + 1) * D, GRP, NT) &&
+                           live_lo((M + 1) * D, GRP, NT) >= live_hi((M + 1) * D, GRP, NT)) || (M + 1) * D >= 208,
+                "skipped taps must be dead");
   const char* hb = pad_base(smem, lane);
   bf16v8 cur[NT];
 #pragma unroll
@@ -349,7 +353,8 @@ __device__ __forceinline__ void store_h8(char* smem, int p, int ch0, const f32x4
 // squares in the upper half-wave); v_permlane16_swap on a PAIR of tiles (lanes +-16: row 0/1 = sum of tile a/b,
 // row 2/3 = sum of squares of tile a/b), so every lane ends with one finished statistic; four partials through LDS.
 // Two barriers inside when do_ln; the first also orders "all MFMA reads of the old h image" before its overwrite.
-template <int NT, bool ASSIGN>
+// FAST (L > 192): only tile 12 holds positions >= L, the store guard of every other tile folds away.
+template <int NT, bool ASSIGN, bool FAST>
 __device__ __forceinline__ void epilogue_ln(char* smem, f32x4 (&feat)[NT][2], const f32x4 (&acc)[NT][2], const float* blk,
                                             const float* tbv_src, bool do_ln, int L, int lane, int ct, int grp) {
 #pragma clang fp contract(fast)
@@ -415,7 +420,7 @@ __device__ __forceinline__ void epilogue_ln(char* smem, f32x4 (&feat)[NT][2], co
     for (int s = 0; s < 2; ++s)
 #pragma unroll
       for (int i = 0; i < 4; ++i) hv[s][i] = ((feat[t][s][i] + tbv[s][i]) * rstd + c) * gv[s][i] + bv[s][i];
-    if (p < L) store_h8(smem, p, ch0, hv);
+    if ((FAST && grp + 2 * t < 12) || p < L) store_h8(smem, p, ch0, hv);
   }
   __syncthreads();
 }
@@ -481,7 +486,9 @@ __device__ __forceinline__ void sample_body(const SampleArgs& a, char* smem, int
   auto dil_of = [&](int layer) { return (int)((a.dilpk[layer >> 3] >> (8 * (layer & 7))) & 255ull); };
   auto reach_of = [&](int layer) {
     const int d = dil_of(layer);
-    if (FAST) return d == 64 ? 3 : 4;
+    // (FAST, dilation 64: the taps shifted by +-192 have no live tile among the odd tiles, so waves 4-7 skip them
+    // altogether, weight fetch included; waves 0-3 keep tile 12 / tile 0)
+    if (FAST) return d == 64 ? (GRP == 1 ? 2 : 3) : 4;
     const int m = (d > 0) ? (L - 1) / d : 4;
     return m < 4 ? m : 4;
   };
@@ -558,7 +565,7 @@ __device__ __forceinline__ void sample_body(const SampleArgs& a, char* smem, int
         acc[t][1] = s1;
       }
     }
-    epilogue_ln<NT, true>(smem, feat, acc, vecs, tbl, true, L, lane, ct, grp);
+    epilogue_ln<NT, true, FAST>(smem, feat, acc, vecs, tbl, true, L, lane, ct, grp);
     if (a.dbg_feat && f == a.dump_fwd && a.dbg_layer == -1) dump_feat<NT>(a.dbg_feat, b, L, feat, lane, ct, grp);
     ACCUM(3, t0);
 
@@ -578,7 +585,7 @@ __device__ __forceinline__ void sample_body(const SampleArgs& a, char* smem, int
       const char* wafter = wlane + (long)after * TAP_BYTES;
       if constexpr (FAST) {
         if (dil == 64) {          // m == 3
-          static_layer<NT, GRP, 64, 3>(smem, wn, wafter, ring, lane, acc);
+          static_layer<NT, GRP, 64, (GRP == 1 ? 2 : 3)>(smem, wn, wafter, ring, lane, acc);
         } else if (dil == 16) {   // m == 4
           static_layer<NT, GRP, 16, 4>(smem, wn, wafter, ring, lane, acc);
         } else {                  // dilation <= 4: every shift stays within the zero padding
@@ -607,7 +614,7 @@ __device__ __forceinline__ void sample_body(const SampleArgs& a, char* smem, int
         mma_tap<NT, false>(smem, wafter, ring, 0, L, lane, grp, bp, cur, acc);
       }
       ACCUM(0, t0);
-      epilogue_ln<NT, false>(smem, feat, acc, vecs + 384 * (layer + 1), tbl + 128 * (layer + 1), layer + 1 < a.n_layers,
+      epilogue_ln<NT, false, FAST>(smem, feat, acc, vecs + 384 * (layer + 1), tbl + 128 * (layer + 1), layer + 1 < a.n_layers,
                              L, lane, ct, grp);
       if (a.dbg_feat && f == a.dump_fwd && a.dbg_layer == layer) dump_feat<NT>(a.dbg_feat, b, L, feat, lane, ct, grp);
       ACCUM(2, t0);
@@ -622,7 +629,7 @@ __device__ __forceinline__ void sample_body(const SampleArgs& a, char* smem, int
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const int p = 16 * (grp + 2 * t) + pn_h;
-        if (p < L) store_h8(smem, p, ch_h, feat[t]);
+        if ((FAST && grp + 2 * t < 12) || p < L) store_h8(smem, p, ch_h, feat[t]);
         acc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f};
         acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
@@ -657,7 +664,7 @@ __device__ __forceinline__ void sample_body(const SampleArgs& a, char* smem, int
         for (int s = 0; s < 2; ++s)
 #pragma unroll
           for (int i = 0; i < 4; ++i) hv[s][i] = fmaxf(acc[t][s][i] + hb0[s][i], 0.f);
-        if (p < L) store_h8(smem, p, ch2, hv);
+        if ((FAST && grp + 2 * t < 12) || p < L) store_h8(smem, p, ch2, hv);
       }
     }
     __syncthreads();
