@@ -182,9 +182,15 @@ __device__ __forceinline__ const char* pad_base(const char* smem, int lane) {
   return smem + (OFF_HB - HPAD * ROWB) + pn * ROWB + 128 * ((lo >> 4) & 1) + 64 * (lo >> 5);
 }
 
+// Weight fragment load with a wave-uniform base (SGPR pair) and a 32-bit per-lane offset: the compiler then uses the
+// scalar-base form of global_load and moves tap / k-step strides to the scalar unit, instead of 64-bit VALU adds.
+__device__ __forceinline__ bf16v8 wload(const char* __restrict__ wu, unsigned loff) {
+  return *(const bf16v8*)(wu + (size_t)loff);
+}
+
 // mma_tap for dilation <= 4 (every shift within HPAD rows): hcur / hnext = pad_base shifted by this / the next tap.
 template <int NT, int GRP, bool HAS_NEXT>
-__device__ __forceinline__ void mma_tap_pad(const char* hcur, const char* hnext, const char* __restrict__ wnext,
+__device__ __forceinline__ void mma_tap_pad(const char* hcur, const char* hnext, const char* __restrict__ wnext, unsigned loff,
                                             bf16v8 (&ring)[8], bf16v8 (&cur)[NT], f32x4 (&acc)[NT][2]) {
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
@@ -198,8 +204,8 @@ __device__ __forceinline__ void mma_tap_pad(const char* hcur, const char* hnext,
       else if (HAS_NEXT)
         cur[t] = *(const bf16v8*)(hnext + RI(GRP, t, 0));
     }
-    ring[2 * ks] = *(const bf16v8*)(wnext + ks * KSTEP_BYTES);
-    ring[2 * ks + 1] = *(const bf16v8*)(wnext + ks * KSTEP_BYTES + SUB_BYTES);
+    ring[2 * ks] = wload(wnext + ks * KSTEP_BYTES, loff);
+    ring[2 * ks + 1] = wload(wnext + ks * KSTEP_BYTES + SUB_BYTES, loff);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
@@ -232,7 +238,7 @@ __host__ __device__ constexpr int live_hi(int off, int grp, int nt) {   // one p
 // tap's range [N0, N1) are fetched (shift OFFN).  hb = pad_base: a live tile's shifted rows are rows of the image (or
 // its zero rows 200..207), so every address is hb + a constant.  Otherwise as mma_tap.
 template <int NT, int GRP, int OFF, int T0, int T1, int OFFN, int N0, int N1>
-__device__ __forceinline__ void mma_tap_static(const char* hb, const char* __restrict__ wnext, bf16v8 (&ring)[8],
+__device__ __forceinline__ void mma_tap_static(const char* hb, const char* __restrict__ wnext, unsigned loff, bf16v8 (&ring)[8],
                                                bf16v8 (&cur)[NT], f32x4 (&acc)[NT][2]) {
   if constexpr (T1 - T0 >= 1 && T1 - T0 <= 2) {
     // One or two live tiles: 2-4 MFMAs per k-step cannot cover an LDS read, so all of the tap's fragments are
@@ -255,8 +261,8 @@ __device__ __forceinline__ void mma_tap_static(const char* hb, const char* __res
         acc[T0 + t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b, acc[T0 + t][0], 0, 0, 0);
         acc[T0 + t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b, acc[T0 + t][1], 0, 0, 0);
       }
-      ring[2 * ks] = *(const bf16v8*)(wnext + ks * KSTEP_BYTES);
-      ring[2 * ks + 1] = *(const bf16v8*)(wnext + ks * KSTEP_BYTES + SUB_BYTES);
+      ring[2 * ks] = wload(wnext + ks * KSTEP_BYTES, loff);
+      ring[2 * ks + 1] = wload(wnext + ks * KSTEP_BYTES + SUB_BYTES, loff);
     }
 #pragma unroll
     for (int t = T0; t < T1; ++t)
@@ -281,8 +287,8 @@ __device__ __forceinline__ void mma_tap_static(const char* hb, const char* __res
         cur[t] = *(const bf16v8*)(hb + RI(GRP, t, OFFN));
       }
     }
-    ring[2 * ks] = *(const bf16v8*)(wnext + ks * KSTEP_BYTES);
-    ring[2 * ks + 1] = *(const bf16v8*)(wnext + ks * KSTEP_BYTES + SUB_BYTES);
+    ring[2 * ks] = wload(wnext + ks * KSTEP_BYTES, loff);
+    ring[2 * ks + 1] = wload(wnext + ks * KSTEP_BYTES + SUB_BYTES, loff);
     // pinned issue order, as in mma_tap: (reads of tiles only the next tap uses,) then per live tile two MFMAs and the
     // read that replaces its fragment, then the two ring refills
     if (ks + 1 == 4) {
@@ -301,19 +307,19 @@ __device__ __forceinline__ void mma_tap_static(const char* hb, const char* __res
 // Taps K .. M of a layer with static dilation D (shift K*D), each with its own live range; wn = this lane's pointer to
 // the weights of tap K+1, wafter = to the tap that follows the layer's last.
 template <int NT, int GRP, int D, int M, int K>
-__device__ __forceinline__ void static_taps(const char* hb, const char* wn, const char* wafter, bf16v8 (&ring)[8],
+__device__ __forceinline__ void static_taps(const char* hb, const char* wn, const char* wafter, unsigned loff, bf16v8 (&ring)[8],
                                             bf16v8 (&cur)[NT], f32x4 (&acc)[NT][2]) {
   constexpr int off = K * D, offn = (K + 1) * D;
   constexpr bool last = (K == M);
   constexpr int T0 = live_lo(off, GRP, NT), T1 = live_hi(off, GRP, NT);
   constexpr int N0 = last ? 0 : live_lo(offn, GRP, NT), N1 = last ? 0 : live_hi(offn, GRP, NT);
-  mma_tap_static<NT, GRP, off, T0, T1, offn, N0, N1>(hb, last ? wafter : wn, ring, cur, acc);
-  if constexpr (!last) static_taps<NT, GRP, D, M, K + 1>(hb, wn + TAP_BYTES, wafter, ring, cur, acc);
+  mma_tap_static<NT, GRP, off, T0, T1, offn, N0, N1>(hb, last ? wafter : wn, loff, ring, cur, acc);
+  if constexpr (!last) static_taps<NT, GRP, D, M, K + 1>(hb, wn + TAP_BYTES, wafter, loff, ring, cur, acc);
 }
 
 // Whole MMA phase of such a layer: first tap's fragments (the only exposed LDS latency), then the taps.
 template <int NT, int GRP, int D, int M>
-__device__ __forceinline__ void static_layer(const char* smem, const char* wn, const char* wafter, bf16v8 (&ring)[8],
+__device__ __forceinline__ void static_layer(const char* smem, const char* wn, const char* wafter, unsigned loff, bf16v8 (&ring)[8],
                                              int lane, f32x4 (&acc)[NT][2]) {
   constexpr int T0 = live_lo(-M * D, GRP, NT), T1 = live_hi(-M * D, GRP, NT);
   // taps beyond +-M must have no live tile for this wave (the caller skips them, weights included)
@@ -325,7 +331,7 @@ __device__ __forceinline__ void static_layer(const char* smem, const char* wn, c
 #pragma unroll
   for (int t = T0; t < T1; ++t) cur[t] = *(const bf16v8*)(hb + RI(GRP, t, -M * D));
   if (T1 > T0) __builtin_amdgcn_sched_group_barrier(0x100, T1 - T0, 0);   // the k-step-0 reads first, as a group
-  static_taps<NT, GRP, D, M, -M>(hb, wn, wafter, ring, cur, acc);
+  static_taps<NT, GRP, D, M, -M>(hb, wn, wafter, loff, ring, cur, acc);
 }
 
 // This lane's channels: 32 ct + 16 s + 4 g + i (s = 0,1; i = 0..3) <-> register [s][i].
@@ -493,7 +499,9 @@ __device__ __forceinline__ void sample_body(const SampleArgs& a, char* smem, int
     return m < 4 ? m : 4;
   };
   // this lane's pointer to fragment (k-step 0, row tile 0) of tap index `tapidx` (= 9*layer + tap; 9*n_layers = final_conv.0)
-  const char* wlane = a.wfrag + ct * (2 * SUB_BYTES) + lane * 16;
+  const char* wuni = a.wfrag + ct * (2 * SUB_BYTES);   // wave-uniform part, and this lane's 16 bytes of a fragment
+  const unsigned loff = (unsigned)lane * 16u;
+  const char* wlane = wuni + loff;
   const int head0_tap = 9 * a.n_layers;
   const int first_tap = 4 - reach_of(0);
 
@@ -581,13 +589,13 @@ __device__ __forceinline__ void sample_body(const SampleArgs& a, char* smem, int
         acc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f};
         acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
-      const char* wn = wlane + (long)(9 * layer + 4 - m + 1) * TAP_BYTES;
-      const char* wafter = wlane + (long)after * TAP_BYTES;
+      const char* wn = (FAST ? wuni : wlane) + (long)(9 * layer + 4 - m + 1) * TAP_BYTES;   // FAST: uniform base + loff
+      const char* wafter = (FAST ? wuni : wlane) + (long)after * TAP_BYTES;
       if constexpr (FAST) {
         if (dil == 64) {          // m == 3
-          static_layer<NT, GRP, 64, (GRP == 1 ? 2 : 3)>(smem, wn, wafter, ring, lane, acc);
+          static_layer<NT, GRP, 64, (GRP == 1 ? 2 : 3)>(smem, wn, wafter, loff, ring, lane, acc);
         } else if (dil == 16) {   // m == 4
-          static_layer<NT, GRP, 16, 4>(smem, wn, wafter, ring, lane, acc);
+          static_layer<NT, GRP, 16, 4>(smem, wn, wafter, loff, ring, lane, acc);
         } else {                  // dilation <= 4: every shift stays within the zero padding
           const char* hcur = pad_base(smem, lane) - 4 * dil * ROWB;
           const int hstep = dil * ROWB;
@@ -595,11 +603,11 @@ __device__ __forceinline__ void sample_body(const SampleArgs& a, char* smem, int
 #pragma unroll
           for (int t = 0; t < NT; ++t) cur[t] = *(const bf16v8*)(hcur + RI(GRP, t, 0));
           for (int k = 0; k < 8; ++k) {
-            mma_tap_pad<NT, GRP, true>(hcur, hcur + hstep, wn, ring, cur, acc);
+            mma_tap_pad<NT, GRP, true>(hcur, hcur + hstep, wn, loff, ring, cur, acc);
             hcur += hstep;
             wn += TAP_BYTES;
           }
-          mma_tap_pad<NT, GRP, false>(hcur, hcur, wafter, ring, cur, acc);
+          mma_tap_pad<NT, GRP, false>(hcur, hcur, wafter, loff, ring, cur, acc);
         }
       } else {
         const char* bp[NT];
@@ -642,7 +650,7 @@ __device__ __forceinline__ void sample_body(const SampleArgs& a, char* smem, int
       bf16v8 cur[NT];
 #pragma unroll
       for (int t = 0; t < NT; ++t) cur[t] = *(const bf16v8*)(hcur + RI(GRP, t, 0));
-      mma_tap_pad<NT, GRP, false>(hcur, hcur, wlane + (long)first_tap * TAP_BYTES, ring, cur, acc);
+      mma_tap_pad<NT, GRP, false>(hcur, hcur, wuni + (long)first_tap * TAP_BYTES, loff, ring, cur, acc);
     } else {
       const char* bp[NT];
       bf16v8 cur[NT];
