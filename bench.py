@@ -36,14 +36,14 @@ FLOP_PER_POS_FWD = 11520 + 20 * FLOP_PER_POS_LAYER + 34048   # 5.944 MFLOP
 PEAK = {'bf16': 2500.0, 'fp32': 157.3}            # TFLOP/s dense MFMA, MI355X_MICROARCH.md
 # HBM-side bytes of ONE k_sample_bf16 launch at exactly this workload (B=1024, L=200, 129 forwards), from rocprofv3 PMC
 # passes (FETCH_SIZE and WRITE_SIZE in separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md's HBM section prescribes
-# for 16-B-per-lane loads on gfx950): tools/pmc_traffic.sh, summary in profiles/r1_bf16_v7_pmc_traffic.json.  A recorded
+# for 16-B-per-lane loads on gfx950): tools/pmc_traffic.sh, summary in profiles/r1_bf16_v8_pmc_traffic.json.  A recorded
 # measurement (a process cannot collect PMC counters on itself); reported only for the workload it was taken on.
-PMC_TRAFFIC = {('bf16', 1024): {'bytes_per_launch': 27920881088.0, 'fetch_bytes': 27408414464.0, 'write_bytes': 512466624.0,
+PMC_TRAFFIC = {('bf16', 1024): {'bytes_per_launch': 26392558656.0, 'fetch_bytes': 26173237760.0, 'write_bytes': 219320896.0,
                                 'algorithmic_bytes': 7.6e6,
                                 'note': 'L2-to-fabric requests; Infinity-Cache hits are counted: the 5.9 MB bf16 weight '
                                         'stream outgrows a 4 MB per-XCD L2 and is re-fetched from the 256 MB Infinity '
-                                        'Cache; 0.23 TB/s = 2.9 % of HBM peak, the launch is MFMA-bound',
-                                'source': 'profiles/r1_bf16_v7_pmc_traffic.json'}}
+                                        'Cache; 0.24 TB/s = 2.9 % of HBM peak, the launch is MFMA-bound',
+                                'source': 'profiles/r1_bf16_v8_pmc_traffic.json'}}
 
 
 def cpu_baseline(seconds_budget=15.0):

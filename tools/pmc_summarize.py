@@ -13,7 +13,7 @@ out = {'what': 'rocprofv3 --pmc, one counter group per run, over ONE k_sample_bf
                'noise removal = 129 denoiser forwards (python3 tools/pmc_run.py 1024 128)'}
 for f in sorted(glob.glob(f'gpurun_out/pmc_{tag}_*/**/*counter_collection.csv', recursive=True)):
     for r in csv.DictReader(open(f)):
-        if r['Kernel_Name'].startswith('k_sample_bf16'):
+        if 'k_sample_bf16' in r['Kernel_Name']:
             out[r['Counter_Name']] = out.get(r['Counter_Name'], 0.0) + float(r['Counter_Value'])
             out['duration_ms_' + r['Counter_Name']] = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6
             out['scratch_bytes_per_lane'] = int(r['Scratch_Size'])
