@@ -41,6 +41,8 @@
 #include "drk_common.h"
 #include "../../include/drakes_hip.h"
 
+#include <stdlib.h>
+
 typedef __bf16 bf16v8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16v4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
@@ -796,6 +798,7 @@ extern "C" int drk_sample_bf16(const void* wstream, const void* stem_w, const vo
   }
   bool fast = (L > 192 && L <= 208);   // the all-immediate-addressing build (see sample_body)
   for (int i = 0; i < n_layers; ++i) fast = fast && ((dilations[i] >= 1 && dilations[i] <= 4) || dilations[i] == 16 || dilations[i] == 64);
+  if (getenv("DRK_SAMPLE_GENERIC")) fast = false;   // tests: the generic build must give the same bits
   const void* kern = fast ? (const void*)k_sample_bf16<true> : (const void*)k_sample_bf16<false>;
   {  // per device, cheap, and not an allocation: lets the launch ask for more than 64 KB of LDS
     hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);

@@ -42,6 +42,46 @@ def test_fused_forward_logits(gpu_model, dev, det_sd, B, L):
     assert torch.equal(toks.cpu(), want)
 
 
+def test_fused_fast_build_equals_generic_build(gpu_model, dev, monkeypatch):
+    """192 < L <= 208 runs k_sample_bf16<true> (zero-padded image, immediate addressing, static live ranges, waves 4-7
+    without the +-192 taps); DRK_SAMPLE_GENERIC forces k_sample_bf16<false> on the same input.  Both add the same
+    products in the same order (skipped tiles only ever added zeros): logits and sampled tokens must be bit-identical."""
+    gen = np.random.Generator(np.random.PCG64(5))
+    for L in (200, 193, 208):
+        x = torch.from_numpy(gen.integers(0, 5, (4, L))).to(dev)
+        monkeypatch.delenv('DRK_SAMPLE_GENERIC', raising=False)
+        lf, tf = fastpath.backbone_logits_bf16(gpu_model.backbone, x)
+        monkeypatch.setenv('DRK_SAMPLE_GENERIC', '1')
+        lg, tg = fastpath.backbone_logits_bf16(gpu_model.backbone, x)
+        assert torch.equal(lf, lg) and torch.equal(tf, tg), L
+    gpu_model.hip_dtype = 'bf16'
+    try:
+        monkeypatch.delenv('DRK_SAMPLE_GENERIC', raising=False)
+        a = gpu_model._sample(num_steps=24, eval_sp_size=6, seed=77)
+        monkeypatch.setenv('DRK_SAMPLE_GENERIC', '1')
+        b = gpu_model._sample(num_steps=24, eval_sp_size=6, seed=77)
+    finally:
+        gpu_model.hip_dtype = 'fp32'
+    assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('stacks,L', [(1, 200), (1, 100), (2, 208)])
+def test_fused_forward_reduced_depth(dev, stacks, L):
+    """5 and 10 residual layers (num_cnn_stacks = 1, 2): the per-layer tables, the tap stream order and the skip to
+    final_conv.0 do not assume 20 layers."""
+    from drakes_amd.det_init import det_state_dict
+    sd = det_state_dict(11, num_cnn_stacks=stacks)
+    m = drakes_amd.Diffusion(drakes_amd.default_config(length=L, num_cnn_stacks=stacks)).to(dev)
+    m.load_state_dict(sd, strict=True)
+    gen = np.random.Generator(np.random.PCG64(3 + L))
+    x = torch.from_numpy(gen.integers(0, 5, (3, L)))
+    with torch.no_grad():
+        emu = E.cnn_forward_bf16(sd, x, torch.zeros(3)).numpy()
+    logits, _ = fastpath.backbone_logits_bf16(m.backbone, x.to(dev))
+    got = logits.cpu().numpy()
+    assert np.sqrt(((got - emu) ** 2).mean()) < 1e-2 and np.abs(got - emu).max() < 6e-2
+
+
 @pytest.mark.parametrize('layer', [-1, 0, 7, 8, 12, 16, 19])
 def test_fused_single_layer_tight(dev, det_sd, layer):
     """All convs except `layer` zeroed: the stream after it must match the emulation tightly.
