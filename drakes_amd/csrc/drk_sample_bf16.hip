@@ -353,6 +353,30 @@ __device__ __forceinline__ void store_h8(char* smem, int p, int ch0, const f32x4
   }
 }
 
+// Diagnostic build only (-DDRK_STAMPS, tools/exp.py): per-wave cycle shares of the phases, written to dbg_feat as
+// uint64 [B][8 waves][4] = (mma, -, layer epilogue+LayerNorm, stem/head/step).  Never in the product.
+#ifdef DRK_STAMPS
+#define STAMP(var)                                         \
+  do {                                                     \
+    __builtin_amdgcn_sched_barrier(0);                     \
+    var = __builtin_amdgcn_s_memtime();                    \
+    __builtin_amdgcn_s_waitcnt(0xC07F);                    \
+    __builtin_amdgcn_sched_barrier(0);                     \
+  } while (0)
+#define ACCUM(slot, t0v)                                   \
+  do {                                                     \
+    unsigned long long t1__;                               \
+    STAMP(t1__);                                           \
+    tacc[slot] += t1__ - t0v;                              \
+    t0v = t1__;                                            \
+  } while (0)
+#else
+#define STAMP(var) do {} while (0)
+#define ACCUM(slot, t0v) do {} while (0)
+#endif
+
+// The body, specialised on the number of position tiles this wave owns (7 for waves 0-3, 6 or 7 for
+// waves 4-7).  Positions >= L inside a computed tile are never stored.
 // Residual update feat += relu(acc + bias) [or feat = relu(acc + bias) after the stem], then, if `do_ln`, the next
 // layer's LayerNorm of (feat + tbias) over the 128 channels of each position -> h image (bf16).
 // blk: vector block [3][128] in LDS (bias, gamma, beta); tbv_src: the LayerNorm's time bias [128] in LDS.
@@ -364,7 +388,11 @@ __device__ __forceinline__ void store_h8(char* smem, int p, int ch0, const f32x4
 // FAST (L > 192): only tile 12 holds positions >= L, the store guard of every other tile folds away.
 template <int NT, bool ASSIGN, bool FAST>
 __device__ __forceinline__ void epilogue_ln(char* smem, f32x4 (&feat)[NT][2], const f32x4 (&acc)[NT][2], const float* blk,
-                                            const float* tbv_src, bool do_ln, int L, int lane, int ct, int grp) {
+                                            const float* tbv_src, bool do_ln, int L, int lane, int ct, int grp
+#ifdef DRK_STAMPS
+                                            , unsigned long long (&tacc)[6], unsigned long long& t0
+#endif
+                                            ) {
 #pragma clang fp contract(fast)
   const int lo = opaque(lane);
   const int n = lo & 15, g = lo >> 4;
@@ -412,7 +440,9 @@ __device__ __forceinline__ void epilogue_ln(char* smem, f32x4 (&feat)[NT][2], co
   f32x4 gv[2], bv[2];
   load_vec8(blk + 128, ch0, gv);
   load_vec8(blk + 256, ch0, bv);
+  ACCUM(4, t0);   // (stamps build) pass 1 up to the first barrier
   __syncthreads();
+  ACCUM(1, t0);   // the wait at the first barrier
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int p = 16 * (grp + 2 * t) + pn;
@@ -449,30 +479,6 @@ __device__ __forceinline__ void dump_feat(float* __restrict__ dst, long b, int L
   }
 }
 
-// Diagnostic build only (-DDRK_STAMPS, tools/exp.py): per-wave cycle shares of the phases, written to dbg_feat as
-// uint64 [B][8 waves][4] = (mma, -, layer epilogue+LayerNorm, stem/head/step).  Never in the product.
-#ifdef DRK_STAMPS
-#define STAMP(var)                                         \
-  do {                                                     \
-    __builtin_amdgcn_sched_barrier(0);                     \
-    var = __builtin_amdgcn_s_memtime();                    \
-    __builtin_amdgcn_s_waitcnt(0xC07F);                    \
-    __builtin_amdgcn_sched_barrier(0);                     \
-  } while (0)
-#define ACCUM(slot, t0v)                                   \
-  do {                                                     \
-    unsigned long long t1__;                               \
-    STAMP(t1__);                                           \
-    tacc[slot] += t1__ - t0v;                              \
-    t0v = t1__;                                            \
-  } while (0)
-#else
-#define STAMP(var) do {} while (0)
-#define ACCUM(slot, t0v) do {} while (0)
-#endif
-
-// The body, specialised on the number of position tiles this wave owns (7 for waves 0-3, 6 or 7 for
-// waves 4-7).  Positions >= L inside a computed tile are never stored.
 // FAST: 192 < L <= 208 and every dilation in {1..4, 16, 64} (checked by the entry point): every layer runs on
 // immediate addressing (zero-padded image for dilation <= 4, static live ranges for 16 and 64); the generic tap loop is
 // not even compiled in, which also keeps its address registers out of the allocation.
@@ -522,7 +528,7 @@ __device__ __forceinline__ void sample_body(const SampleArgs& a, char* smem, int
     ring[f] = *(const bf16v8*)(wlane + (long)first_tap * TAP_BYTES + (f >> 1) * KSTEP_BYTES + (f & 1) * SUB_BYTES);
 
 #ifdef DRK_STAMPS
-  unsigned long long tacc[4] = {0, 0, 0, 0}, t0;
+  unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, t0;
   STAMP(t0);
   const unsigned long long clk0 = t0, rt0 = __builtin_amdgcn_s_memrealtime();   // shader cycles vs the 100 MHz counter
 #endif
@@ -575,7 +581,11 @@ __device__ __forceinline__ void sample_body(const SampleArgs& a, char* smem, int
         acc[t][1] = s1;
       }
     }
+#ifdef DRK_STAMPS
+    epilogue_ln<NT, true, FAST>(smem, feat, acc, vecs, tbl, true, L, lane, ct, grp, tacc, t0);
+#else
     epilogue_ln<NT, true, FAST>(smem, feat, acc, vecs, tbl, true, L, lane, ct, grp);
+#endif
     if (a.dbg_feat && f == a.dump_fwd && a.dbg_layer == -1) dump_feat<NT>(a.dbg_feat, b, L, feat, lane, ct, grp);
     ACCUM(3, t0);
 
@@ -624,8 +634,13 @@ __device__ __forceinline__ void sample_body(const SampleArgs& a, char* smem, int
         mma_tap<NT, false>(smem, wafter, ring, 0, L, lane, grp, bp, cur, acc);
       }
       ACCUM(0, t0);
+#ifdef DRK_STAMPS
       epilogue_ln<NT, false, FAST>(smem, feat, acc, vecs + 384 * (layer + 1), tbl + 128 * (layer + 1), layer + 1 < a.n_layers,
-                             L, lane, ct, grp);
+                                   L, lane, ct, grp, tacc, t0);
+#else
+      epilogue_ln<NT, false, FAST>(smem, feat, acc, vecs + 384 * (layer + 1), tbl + 128 * (layer + 1), layer + 1 < a.n_layers,
+                                   L, lane, ct, grp);
+#endif
       if (a.dbg_feat && f == a.dump_fwd && a.dbg_layer == layer) dump_feat<NT>(a.dbg_feat, b, L, feat, lane, ct, grp);
       ACCUM(2, t0);
     }
@@ -752,6 +767,8 @@ __device__ __forceinline__ void sample_body(const SampleArgs& a, char* smem, int
   if (a.dbg_feat && lane == 0) {
     unsigned long long* o = (unsigned long long*)a.dbg_feat + (b * 8 + wave) * 4;
     o[0] = tacc[0]; o[1] = __builtin_amdgcn_s_memtime() - clk0; o[2] = tacc[2]; o[3] = tacc[3];
+    ((unsigned long long*)a.dbg_feat)[(long)a.B * 33 + b * 8 + wave] = tacc[1];   // wait at the epilogue's first barrier
+    ((unsigned long long*)a.dbg_feat)[(long)a.B * 41 + b * 8 + wave] = tacc[4];   // epilogue pass 1
     tacc[1] = __builtin_amdgcn_s_memrealtime() - rt0;
     if (wave == 0) ((unsigned long long*)a.dbg_feat)[(long)a.B * 32 + b] = tacc[1];   // 100 MHz ticks of this workgroup
   }

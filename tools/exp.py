@@ -55,14 +55,19 @@ def stamps(B=1024, steps=8):
     raw = dbg.view(torch.int64)
     st = raw[: B * 8 * 4].reshape(B, 8, 4).cpu().numpy().astype(np.float64)
     ticks = raw[B * 32: B * 32 + B].cpu().numpy().astype(np.float64)          # 100 MHz
+    p1 = raw[B * 33: B * 33 + B * 8].reshape(B, 8).cpu().numpy().astype(np.float64)
+    p1c = raw[B * 41: B * 41 + B * 8].reshape(B, 8).cpu().numpy().astype(np.float64)
     cyc = st[:, 0, 1].copy()                                                   # shader cycles of wave 0 over the same span
     print(f'in-kernel clock: {np.median(cyc / ticks) * 0.1:.3f} GHz (median over workgroups; min {np.min(cyc / ticks) * 0.1:.3f}, max {np.max(cyc / ticks) * 0.1:.3f})')
-    st[:, :, 1] = 0
+    st[:, :, 1] = p1
+    st[:, :, 3] += p1c
     tot = st.sum(-1, keepdims=True)
     sh = st / tot
-    names = ['mma', 'stage sync', 'layer epilogue+LN', 'stem/head/step']
+    names = ['mma', 'barrier 1 wait', 'epilogue pass 2 + barrier 2', 'stem/head/step (+ pass 1, listed below)']
     for w in range(8):
         print(f'wave {w}: total {tot[:, w].mean():.3e} cyc  ' + '  '.join(f'{n} {sh[:, w, i].mean()*100:.1f}%' for i, n in enumerate(names)))
+    print('epilogue pass 1 (compute, up to barrier 1), cycles per epilogue, by wave:', (p1c.mean(0) / ((steps + 1) * 21)).round(0))
+    print('wait at barrier 1, cycles per epilogue, by wave:', (p1.mean(0) / ((steps + 1) * 21)).round(0))
     per_fwd_layer = st.mean(0) / ((steps + 1) * 20)
     print('cycles per layer (avg over waves):', per_fwd_layer.mean(0)[:3], ' per forward other:', st.mean(0).mean(0)[3] / (steps + 1))
 
