@@ -398,32 +398,42 @@ __device__ __forceinline__ void epilogue_ln(char* smem, f32x4 (&feat)[NT][2], co
   const int n = lo & 15, g = lo >> 4;
   const int pn = n ^ ((n & 8) >> 1);
   const int ch0 = 32 * ct + 4 * g;
-  f32x4 cb[2], tbv[2];
-  load_vec8(blk, ch0, cb);
+  // Written on whole f32x4 values so that the adds and the fused multiply-adds come out packed (v_pk_add_f32 /
+  // v_pk_fma_f32, two channels per instruction): this pass shares the SIMD's vector issue with the other wave's MFMAs.
+  // ASSIGN (stem): acc holds the bare sum and the bias is added here (keeps the stem bit-equal to its reference);
+  // otherwise the conv bias is already in acc (the accumulators START at the bias).
+  f32x4 tbv[2];
   if (do_ln) load_vec8(tbv_src, ch0, tbv);
+  // ReLU as a signed-integer max with 0 on the bit pattern (negative floats and -0.0 are negative integers): one
+  // v_max_i32 per value; a float max straight on MFMA results costs a canonicalising second instruction.
+  auto relu4 = [](f32x4 v) __attribute__((always_inline)) {
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    const i32x4 z = {0, 0, 0, 0};
+    return __builtin_bit_cast(f32x4, __builtin_elementwise_max(__builtin_bit_cast(i32x4, v), z));
+  };
+  if constexpr (ASSIGN) {
+    f32x4 cb[2];
+    load_vec8(blk, ch0, cb);
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
+      for (int s = 0; s < 2; ++s) feat[t][s] = relu4(acc[t][s] + cb[s]);
+  } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float r = fmaxf(acc[t][s][i] + cb[s][i], 0.f);
-        feat[t][s][i] = ASSIGN ? r : feat[t][s][i] + r;
-      }
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) feat[t][s] += relu4(acc[t][s]);
+  }
   if (!do_ln) return;
   float* part = (float*)(smem + OFF_PART);
   float y[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float x = feat[t][s][i] + tbv[s][i];
-        s1 += x;
-        s2 += x * x;
-      }
+    const f32x4 x0 = feat[t][0] + tbv[0], x1 = feat[t][1] + tbv[1];
+    const f32x4 sv = x0 + x1;
+    const f32x4 qv = x0 * x0 + x1 * x1;
+    const float s1 = (sv[0] + sv[1]) + (sv[2] + sv[3]);
+    const float s2 = (qv[0] + qv[1]) + (qv[2] + qv[3]);
     const u32x2 sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(s1), __float_as_uint(s2), false, false);
     // lower half-wave: s1(lower) + s1(upper); upper half-wave: s2(lower) + s2(upper)
     y[t] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
@@ -596,10 +606,14 @@ __device__ __forceinline__ void sample_body(const SampleArgs& a, char* smem, int
       const int m = m_next;                                  // one integer division per layer, not per tap
       m_next = (layer + 1 < a.n_layers) ? reach_of(layer + 1) : 0;
       const int after = (layer + 1 < a.n_layers) ? 9 * (layer + 1) + 4 - m_next : head0_tap;   // the tap after this layer's last
+      {   // the accumulators start at the conv bias (this lane's 8 channels): one add per value less in the epilogue
+        f32x4 cbl[2];
+        load_vec8(vecs + 384 * (layer + 1), 32 * ct + 4 * (opaque(lane) >> 4), cbl);
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        acc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-        acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < NT; ++t) {
+          acc[t][0] = cbl[0];
+          acc[t][1] = cbl[1];
+        }
       }
       const char* wn = (FAST ? wuni : wlane) + (long)(9 * layer + 4 - m + 1) * TAP_BYTES;   // FAST: uniform base + loff
       const char* wafter = (FAST ? wuni : wlane) + (long)after * TAP_BYTES;
