@@ -1,21 +1,34 @@
 """bench.py — throughput of the reverse-sampling hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--dtype bf16|fp32] [--batch 1024]
+    python bench.py --gpus N --steps K --warmup W [--dtype bf16|fp32] [--batch 1024] [--workload sample|long|finetune]
 
 One "step" = one full `Diffusion._sample` call (128 reverse steps + the noise-removal forward
-= 129 denoiser forwards) over a batch of 1024 200-bp sequences per GPU: BASELINE.json config 2.
+= 129 denoiser forwards) over a batch of 1024 200-bp sequences per GPU: BASELINE.json configs[1].
 Weights are random-init (default torch init of the reference architecture), data is synthetic
 (the sampler starts from the all-mask state), RNG is the in-kernel Philox stream.
 
-N > 1: launched by torch.distributed.run, one rank per GPU; each rank samples its own shard of
-the global batch (rows keyed by GLOBAL sample index, no data-path collective) -> weak scaling.
+N > 1: one rank per GPU, each sampling its own shard of the global batch (rows keyed by GLOBAL sample
+index, no data-path collective) -> weak scaling.  Two ways in, same code after the rendezvous:
+  * under torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment);
+  * plain `python bench.py --gpus N`: this process starts N children itself (one per LOCAL_RANK, rendezvous on
+    127.0.0.1) BEFORE it makes any GPU call, waits, relays rank 0's JSON line and exits non-zero if any child does.
+The collective backend is 'nccl' (= RCCL over xGMI).  On a box with fewer GPUs than ranks (the one-GPU rehearsal)
+the ranks share a device and the group falls back to 'gloo', because two RCCL ranks cannot share a GPU; the line
+says so in `collective`.
 
-Prints ONE JSON line on rank 0 with `roofline` (dominant kernel, HIP-event timed inside the
-timed region) and `cpu_baseline` (the CPU oracle on a bounded sample of the same workload).
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel, HIP-event timed inside the timed region),
+`cpu_baseline` (the CPU oracle on a bounded sample of the same workload, N=1 only) and `collective`
+(`ranks_seen` = an all_reduce of ones over the group: proof the collective library saw every rank).
+
+Other workloads (not the driver's headline; same JSON shape, their own metric names):
+  --workload long      BASELINE.json configs[4] on one GPU: L=1024, 512 steps, hipGraph-free layer-per-launch bf16 kernels
+  --workload finetune  BASELINE.json configs[2]: `_sample_finetune_gradient` (K=50) + backward, batch 128
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,21 +37,19 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import drakes_amd  # noqa: E402
-from drakes_amd import ops  # noqa: E402
-
 L = 200
 NUM_STEPS = 128
-FORWARDS = NUM_STEPS + 1
 # Dense FLOP count as the reference computes it
 FLOP_PER_POS_LAYER = 2 * 128 * 128 * 9            # 294 912
 FLOP_PER_POS_FWD = 11520 + 20 * FLOP_PER_POS_LAYER + 34048   # 5.944 MFLOP
 PEAK = {'bf16': 2500.0, 'fp32': 157.3}            # TFLOP/s dense MFMA, MI355X_MICROARCH.md
 # HBM-side bytes of ONE k_sample_bf16 launch at exactly this workload (B=1024, L=200, 129 forwards), from rocprofv3 PMC
 # passes (FETCH_SIZE and WRITE_SIZE in separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md's HBM section prescribes
-# for 16-B-per-lane loads on gfx950): tools/pmc_traffic.sh, summary in profiles/r1_bf16_v8_pmc_traffic.json.  A recorded
-# measurement (a process cannot collect PMC counters on itself); reported only for the workload it was taken on.
-PMC_TRAFFIC = {('bf16', 1024): {'bytes_per_launch': 26392558656.0, 'fetch_bytes': 26173237760.0, 'write_bytes': 219320896.0,
+# for 16-B-per-lane loads on gfx950): tools/pmc_traffic.sh.  A recorded measurement (a process cannot collect PMC
+# counters on itself): it names the library version it was taken on and is printed ONLY when drk_version() still is
+# that version — a changed kernel reports traffic null until the passes are re-run.
+PMC_TRAFFIC = {('bf16', 1024): {'drk_version': 109,
+                                'bytes_per_launch': 26392558656.0, 'fetch_bytes': 26173237760.0, 'write_bytes': 219320896.0,
                                 'algorithmic_bytes': 7.6e6,
                                 'note': 'L2-to-fabric requests; Infinity-Cache hits are counted: the 5.9 MB bf16 weight '
                                         'stream outgrows a 4 MB per-XCD L2 and is re-fetched from the 256 MB Infinity '
@@ -46,28 +57,234 @@ PMC_TRAFFIC = {('bf16', 1024): {'bytes_per_launch': 26392558656.0, 'fetch_bytes'
                                 'source': 'profiles/r1_bf16_v8_pmc_traffic.json'}}
 
 
-def cpu_baseline(seconds_budget=15.0):
-    """The CPU oracle (a restatement pinned bit-for-bit to the reference, oracle/make_golden.py)
-    on the host cores: same 128-step schedule, a bounded batch."""
+def _median(v):
+    v = sorted(v)
+    return v[len(v) // 2]
+
+
+def cpu_baseline():
+    """The CPU oracle (a restatement pinned bit-for-bit to the reference, oracle/make_golden.py) on the host cores,
+    as BASELINE.md section 3 prescribes: configs[0] = batch 64, 128 steps + noise removal, L=200, all the cores this
+    process may use, 1 warm-up, median of 3 full calls."""
     from drakes_amd.det_init import det_state_dict
     from oracle import drakes_oracle as O
     from oracle import philox
     sd = det_state_dict(0)
     uni = lambda i, shp: torch.from_numpy(philox.step_uniforms(1, i, shp[0], shp[1]))
     cores = torch.get_num_threads()
+    B = 64
     t0 = time.perf_counter()
-    O.sample(sd, 2, L, 4, uni)                      # warm-up / first-touch
+    O.sample(sd, B, L, 8, uni)                      # warm-up at the timed shape (thread pool, first touch), 8 steps
     warm = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    O.sample(sd, 16, L, NUM_STEPS, uni)             # sizing run: how many sequences fit the budget
-    probe = time.perf_counter() - t0
-    B = int(max(16, min(512, 16 * seconds_budget / max(probe, 1e-3)))) // 16 * 16
-    t0 = time.perf_counter()
-    O.sample(sd, B, L, NUM_STEPS, uni)
-    dt = time.perf_counter() - t0
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        O.sample(sd, B, L, NUM_STEPS, uni)
+        ts.append(time.perf_counter() - t0)
+    dt = _median(ts)
     return {'value': B / dt, 'unit': 'sequences/sec', 'cores': cores, 'kind': 'port',
-            'sample': f'oracle.sample, batch {B}, 128 steps + noise removal, L=200, fp32 torch CPU, '
-                      f'{cores} threads, {dt:.1f} s (warm-up {warm:.1f} s)'}
+            'sample': f'oracle.sample (configs[0]), batch {B}, 128 steps + noise removal, L=200, fp32 torch CPU, '
+                      f'{cores} threads; 1 warm-up ({warm:.1f} s, 8 steps), median of 3 calls: '
+                      + ', '.join(f'{t:.2f}' for t in ts) + ' s'}
+
+
+# ---------------------------------------------------------------------------------------------- self-launch
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n):
+    """Starts one child per rank (what torch.distributed.run would do), relays rank 0's stdout, returns the exit code.
+    Runs before this process has touched the GPU: the parent never initialises HIP."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0', PYTHONUNBUFFERED='1')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        out0 = procs[0].communicate()[0].decode(errors='replace')
+        for p in procs:
+            p.wait()
+            rc = rc or p.returncode
+    finally:
+        for p in procs:                               # our own children, by PID
+            if p.poll() is None:
+                p.kill()
+                rc = rc or 1
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    if rc:
+        print(f'bench.py: a rank exited with {rc}', file=sys.stderr)
+    return rc
+
+
+def _rccl_world1_probe(dev):
+    """N=1: join an 'nccl' (RCCL) group of one rank and push (a) a one, (b) a gradient-bucket-sized fp32 tensor through
+    all_reduce, so that the library the N>1 runs depend on is loaded and exercised on this box too."""
+    import torch.distributed as dist
+    info = {'backend': 'nccl', 'world': 1}
+    try:
+        dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{_free_port()}', rank=0, world_size=1, device_id=dev)
+        one = torch.ones(1, device=dev)
+        dist.all_reduce(one)
+        info['ranks_seen'] = int(one.item())
+        flat = torch.ones(3326597, dtype=torch.float32, device=dev)     # the fine-tune gradient bucket (13.3 MB)
+        dist.all_reduce(flat)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            dist.all_reduce(flat)
+        torch.cuda.synchronize()
+        info['allreduce_13MB_us'] = (time.perf_counter() - t0) / 5 * 1e6
+        info['ok'] = bool(flat[0].item() == 1.0)
+        dist.destroy_process_group()
+    except Exception as e:                              # a box without a usable RCCL must not lose the bench line
+        info['ok'] = False
+        info['error'] = f'{type(e).__name__}: {e}'[:300]
+    return info
+
+
+# ---------------------------------------------------------------------------------------------- workloads
+def workload_sample(args, model, rank, world, barrier):
+    import drakes_amd
+    from drakes_amd import fastpath, ops
+    B = args.batch
+    seed = 1234
+
+    def one_step(k):
+        return model._sample(eval_sp_size=B, seed=seed + k, sample_offset=rank * B)
+
+    for k in range(args.warmup):
+        one_step(k)
+    ops.PROFILE.enable(every=8 if args.dtype == 'fp32' else 1)
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        toks = one_step(args.warmup + k)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = ops.PROFILE.disable()
+    assert toks.shape == (B, L) and int(toks.max()) <= 3 and int(toks.min()) >= 0
+    name, n_timed, avg_ms, flop_per_launch = prof
+    achieved = flop_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms else None
+    roof = {'bound': 'mfma', 'kernel': name, 'achieved': achieved, 'peak': PEAK[args.dtype], 'unit': 'TFLOP/s',
+            'frac': (achieved / PEAK[args.dtype]) if achieved else None, 'traffic': None,
+            'launches_timed': n_timed, 'avg_launch_ms': avg_ms, 'flop_per_launch': flop_per_launch,
+            'numerator': 'dense algorithmic FLOPs, as the reference computes them (BASELINE.md section 4)'}
+    if args.dtype == 'bf16':
+        # what the kernel's MFMAs actually execute: dead (tile, tap) pairs are skipped, L=200 is padded to 208
+        ex = fastpath.executed_flop_fraction(model.backbone, L)
+        roof['executed_flop_frac'] = ex
+        roof['frac_executed'] = roof['frac'] * ex if roof['frac'] else None
+    rec = PMC_TRAFFIC.get((args.dtype, B))
+    if rec is not None:
+        from drakes_amd import _lib
+        ver = _lib.load().drk_version()
+        if rec['drk_version'] == ver:
+            roof['traffic'] = rec['bytes_per_launch']
+            roof['traffic_detail'] = rec
+        else:
+            roof['traffic_detail'] = {'stale': f"recorded on library version {rec['drk_version']}, this is {ver}: "
+                                               're-run tools/pmc_traffic.sh'}
+    out = {'metric': 'sequences/sec, 128-step sampling of 200bp DNA, batch 1024, at 1/2/4/8 MI355X',
+           'value': world * B * args.steps / elapsed, 'unit': 'sequences/sec',
+           'dtype': 'bf16' if args.dtype == 'bf16' else 'f32',
+           'data': 'synthetic (all-mask prior, random-init weights, in-kernel Philox noise)',
+           'config': {'workload': 'configs[1]: Diffusion._sample, CNN denoiser (reference has no DiT), '
+                                  '128 steps + noise removal, L=200, batch 1024 per GPU',
+                      'global_batch': world * B, 'seq_len': L, 'parallelism': f'dp{world} (batch shards, no collective)'},
+           'roofline': roof}
+    return out, elapsed
+
+
+def secondary_fp32(model, B=1024):
+    """The token-exact fp32 path on the same workload, in the same run: one warm-up call, one timed call."""
+    model.hip_dtype = 'fp32'
+    try:
+        model._sample(eval_sp_size=64, seed=1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        model._sample(eval_sp_size=B, seed=2)
+        torch.cuda.synchronize()
+        return B / (time.perf_counter() - t0)
+    finally:
+        model.hip_dtype = 'bf16'
+
+
+def workload_long(args, rank, world, dev, barrier):
+    """configs[4] per GPU: L=1024, 512 steps, bf16 layer kernels (the fused loop holds L <= 224)."""
+    import drakes_amd
+    from drakes_amd import ops
+    Ll, steps, B = 1024, 512, args.batch if args.batch != 1024 else 256
+    m = drakes_amd.Diffusion(drakes_amd.default_config(length=Ll, steps=steps)).to(dev).eval()
+    m.hip_dtype = args.dtype
+    m.hip_graph = True
+    for k in range(args.warmup):
+        m._sample(eval_sp_size=B, seed=k, sample_offset=rank * B)
+    ops.PROFILE.enable(every=97)
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        m._sample(eval_sp_size=B, seed=10 + k, sample_offset=rank * B)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    name, n, ms, fl = ops.PROFILE.disable()
+    rows = B * Ll
+    roof = {'bound': 'hbm', 'kernel': name, 'launches_timed': n, 'avg_launch_ms': ms}
+    if ms and name and 'layer' in name:
+        per_row = getattr(ops, 'LAYER_BYTES_PER_ROW', 1536)
+        roof.update({'achieved': rows * per_row / (ms * 1e-3) / 1e9, 'peak': 8000.0, 'unit': 'GB/s', 'traffic': None,
+                     'bytes_per_row': per_row, 'TFLOPs_dense': fl / ms / 1e9})
+        roof['frac'] = roof['achieved'] / roof['peak']
+    out = {'metric': 'sequences/sec, 512-step sampling of 1024bp sequences (configs[4], per-GPU replica)',
+           'value': world * B * args.steps / elapsed, 'unit': 'sequences/sec', 'dtype': 'bf16' if args.dtype == 'bf16' else 'f32',
+           'data': 'synthetic (all-mask prior, random-init weights, in-kernel Philox noise)',
+           'config': {'workload': f'configs[4]: Diffusion._sample, L={Ll}, {steps} steps + noise removal, batch {B} per GPU, '
+                                  'captured step (hipGraph)', 'global_batch': world * B, 'seq_len': Ll,
+                      'parallelism': f'dp{world} (replicas, no collective)'},
+           'roofline': roof}
+    return out, elapsed
+
+
+def workload_finetune(args, rank, world, dev, barrier):
+    """configs[2]: `_sample_finetune_gradient` (78 hard + 50 soft steps) + backward of a synthetic linear reward."""
+    import drakes_amd
+    B = args.batch if args.batch != 1024 else 128
+    cfg = drakes_amd.default_config(length=L, steps=NUM_STEPS, truncate_steps=50)
+    m = drakes_amd.Diffusion(cfg).to(dev).train()
+    m.hip_dtype = args.dtype
+    rw = torch.randn(B, 4, L, device=dev)
+
+    def one(k):
+        m.zero_grad(set_to_none=True)
+        out = m._sample_finetune_gradient(eval_sp_size=B, seed=100 + k, sample_offset=rank * B)[0]
+        (-(out.permute(0, 2, 1) * rw).sum((1, 2)).mean()).backward()
+
+    for k in range(args.warmup):
+        one(k)
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        one(args.warmup + k)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    # dense FLOPs: 128 forwards + 50 x (input-gradient + weight-gradient convs) = 128 + 100 forward-equivalents
+    flop = B * L * FLOP_PER_POS_FWD * (NUM_STEPS + 2 * 50)
+    per = elapsed / args.steps
+    out = {'metric': 'fine-tune sampling passes/sec (configs[2]: _sample_finetune_gradient K=50 + backward, batch 128)',
+           'value': world * args.steps / elapsed, 'unit': 'passes/sec', 'dtype': 'bf16' if args.dtype == 'bf16' else 'f32',
+           'data': 'synthetic (random-init weights, linear reward, in-kernel Philox noise)',
+           'config': {'workload': f'configs[2]: batch {B} per GPU, L=200, 128 steps, K=50', 'global_batch': world * B,
+                      'seq_len': L, 'parallelism': f'dp{world}'},
+           'seconds_per_pass': per, 'peak_mem_GiB': torch.cuda.max_memory_allocated() / 2 ** 30,
+           'roofline': {'bound': 'mfma', 'kernel': 'whole pass', 'achieved': flop / per / 1e12, 'peak': PEAK[args.dtype],
+                        'unit': 'TFLOP/s', 'frac': flop / per / 1e12 / PEAK[args.dtype], 'traffic': None}}
+    return out, elapsed
 
 
 def main():
@@ -77,36 +294,41 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--batch', type=int, default=1024, help='sequences per GPU')
+    ap.add_argument('--workload', default='sample', choices=['sample', 'long', 'finetune'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-secondary', action='store_true')
     args = ap.parse_args()
+
+    if 'WORLD_SIZE' not in os.environ and (args.gpus > 1 or os.environ.get('DRK_BENCH_SPAWN')):
+        raise SystemExit(spawn_ranks(args.gpus))           # no GPU call has been made in this process
 
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     if world != args.gpus:
-        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
-    local_rank = local_rank % max(torch.cuda.device_count(), 1)   # only differs in the one-GPU rehearsal
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    n_dev = max(torch.cuda.device_count(), 1)               # device_count() does not initialise the GPU
+    shared_device = world > n_dev                           # the one-GPU rehearsal: ranks share a card
+    local_rank = local_rank % n_dev
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    backend = os.environ.get('DRK_BENCH_BACKEND', 'nccl')   # 'gloo': rehearsal of the N>1 path on a one-GPU box
+    backend = os.environ.get('DRK_BENCH_BACKEND') or ('gloo' if shared_device else 'nccl')
+    collective = {'backend': backend, 'world': world}
     if world > 1:
         import torch.distributed as dist
         if backend == 'nccl':
             dist.init_process_group('nccl', device_id=dev)        # RCCL over xGMI
         else:
             dist.init_process_group(backend)
+        ones = torch.ones(1, device=dev if backend == 'nccl' else 'cpu')
+        dist.all_reduce(ones)
+        collective['ranks_seen'] = int(ones.item())
+        if shared_device:
+            collective['note'] = f'{world} ranks share {n_dev} GPU(s): rehearsal, RCCL needs one device per rank'
+        assert collective['ranks_seen'] == world
 
+    import drakes_amd
     torch.manual_seed(0)
-    model = drakes_amd.Diffusion(drakes_amd.default_config(length=L, steps=NUM_STEPS)).to(dev).eval()
-    model.hip_dtype = args.dtype
-    B = args.batch
-    seed = 1234
-
-    def one_step(k):
-        return model._sample(eval_sp_size=B, seed=seed + k, sample_offset=rank * B)
-
-    for k in range(args.warmup):
-        one_step(k)
 
     def barrier():
         torch.cuda.synchronize()
@@ -114,43 +336,38 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    ops.PROFILE.enable(every=8 if args.dtype == 'fp32' else 1)
-    barrier()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        toks = one_step(args.warmup + k)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    prof = ops.PROFILE.disable()
+    model = None
+    if args.workload == 'sample':
+        model = drakes_amd.Diffusion(drakes_amd.default_config(length=L, steps=NUM_STEPS)).to(dev).eval()
+        model.hip_dtype = args.dtype
+        out, elapsed = workload_sample(args, model, rank, world, barrier)
+    elif args.workload == 'long':
+        out, elapsed = workload_long(args, rank, world, dev, barrier)
+    else:
+        out, elapsed = workload_finetune(args, rank, world, dev, barrier)
     if world > 1:
         t = torch.tensor([elapsed], device=dev if backend == 'nccl' else 'cpu', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        out['value'] *= elapsed / t.item()                  # every rank's work over the SLOWEST rank's time
         elapsed = t.item()
-    assert toks.shape == (B, L) and int(toks.max()) <= 3
 
     if rank == 0:
-        total_seqs = world * B * args.steps
-        name, n_timed, avg_ms, flop_per_launch = prof
-        achieved = flop_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms else None
-        out = {
-            'metric': 'sequences/sec, 128-step sampling of 200bp DNA, batch 1024, at 1/2/4/8 MI355X',
-            'value': total_seqs / elapsed, 'unit': 'sequences/sec', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16' if args.dtype == 'bf16' else 'f32',
-            'data': 'synthetic (all-mask prior, random-init weights, in-kernel Philox noise)',
-            'config': {'workload': 'configs[1]: Diffusion._sample, CNN denoiser (reference has no DiT), '
-                                   '128 steps + noise removal, L=200, batch 1024 per GPU',
-                       'global_batch': world * B, 'seq_len': L, 'parallelism': f'dp{world} (batch shards, no collective)'},
-            'roofline': {'bound': 'mfma', 'kernel': name, 'achieved': achieved, 'peak': PEAK[args.dtype],
-                         'unit': 'TFLOP/s', 'frac': (achieved / PEAK[args.dtype]) if achieved else None,
-                         'traffic': (PMC_TRAFFIC.get((args.dtype, B)) or {}).get('bytes_per_launch'),
-                         'traffic_detail': PMC_TRAFFIC.get((args.dtype, B)),
-                         'launches_timed': n_timed, 'avg_launch_ms': avg_ms, 'flop_per_launch': flop_per_launch},
-        }
-        if not args.no_cpu_baseline and world == 1:      # rank 0, N=1 only
-            out['cpu_baseline'] = cpu_baseline()
-        print(json.dumps(out), flush=True)
+        line = {'metric': out.pop('metric'), 'value': out.pop('value'), 'unit': out.pop('unit'), 'n_gpus': world,
+                'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
+                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None}
+        line.update(out)
+        if world == 1:
+            collective = _rccl_world1_probe(dev)
+            if args.workload == 'sample' and args.dtype == 'bf16' and not args.no_secondary:
+                line['secondary'] = {'fp32_token_exact_seq_per_s': secondary_fp32(model),
+                                     'note': 'same workload (B=1024, 128 steps + noise removal) on the exact-fp32 kernels, '
+                                             'whose tokens equal the reference bit for bit; 1 warm-up + 1 timed call'}
+            if not args.no_cpu_baseline and args.workload == 'sample':      # rank 0, N=1 only
+                line['cpu_baseline'] = cpu_baseline()
+        line['collective'] = collective
+        print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

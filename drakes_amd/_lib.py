@@ -18,7 +18,7 @@ _P = c_void_p
 SIGNATURES = {
     'drk_step_uniforms': [_P, c_int, c_int, c_uint64, c_uint32, c_uint64, _P],
     'drk_subs_fwd': [_P, _P, _P, _P, c_int, c_int, _P],
-    'drk_reverse_step_hard': [_P, _P, _P, _P, c_int, c_int, c_float, c_float, c_uint64, c_uint32, c_uint64, _P],
+    'drk_reverse_step_hard': [_P, _P, _P, _P, c_int, c_int, c_float, c_float, _P, c_uint64, c_uint32, c_uint64, _P],
     'drk_reverse_step_hard_table': [_P, _P, _P, c_int, c_int, _P, _P, _P, _P],
     'drk_reverse_step_hard_wide': [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_uint64,
                                    c_uint32, c_uint64, _P],
@@ -27,7 +27,7 @@ SIGNATURES = {
     'drk_reverse_step_soft_wide_bwd': [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, c_float,
                                        c_float, c_uint64, c_uint32, c_uint64, _P],
     'drk_denoise_argmax': [_P, _P, _P, c_int, c_int, _P],
-    'drk_q_xt': [_P, _P, _P, c_int, c_int, c_float, c_uint64, c_uint32, c_uint64, _P],
+    'drk_q_xt': [_P, _P, _P, c_int, c_int, c_float, _P, c_uint64, c_uint32, c_uint64, _P],
     'drk_likelihood_accum': [_P, _P, _P, c_float, _P, c_int, c_int, _P],
     'drk_time_embed_fwd': [_P, c_int, _P, _P, _P, _P, _P],
     'drk_time_bias_fwd': [_P, c_int, _P, _P, c_int, _P, _P],
@@ -43,9 +43,9 @@ SIGNATURES = {
     'drk_stem_bwd': [_P, _P, _P, _P, _P, _P, c_int, c_int, _P],
     'drk_time_bwd': [_P, _P, c_int, _P, _P, _P, c_int, _P, _P, _P, _P, _P],
     'drk_subs_bwd': [_P, _P, _P, _P, _P, c_int, c_int, _P],
-    'drk_reverse_step_soft_fwd': [_P, _P, _P, _P, _P, c_int, c_int, c_float, c_float, c_float, c_float, c_uint64,
+    'drk_reverse_step_soft_fwd': [_P, _P, _P, _P, _P, c_int, c_int, c_float, c_float, _P, c_float, c_float, c_uint64,
                                   c_uint32, c_uint64, _P],
-    'drk_reverse_step_soft_bwd': [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_float, c_float, c_float, c_float,
+    'drk_reverse_step_soft_bwd': [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_float, c_float, _P, c_float, c_float,
                                   c_uint64, c_uint32, c_uint64, _P],
     'drk_kl_step_fwd': [_P, _P, _P, _P, _P, c_float, _P, c_int, c_int, _P],
     'drk_kl_step_bwd': [_P, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P, c_int, c_int, _P],
@@ -53,7 +53,7 @@ SIGNATURES = {
     'drk_layer_bf16': [_P, _P, _P, _P, _P, _P, _P, c_long, _P, _P, c_int, c_int, c_int, c_int, c_int, _P],
     'drk_ln_fwd_bf16': [_P, _P, c_long, _P, _P, _P, c_int, c_int, _P],
     'drk_sample_bf16': [_P, _P, _P, _P, _P, c_long, _P, _P, _P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, c_int,
-                        c_uint64, c_uint64, _P],
+                        c_uint64, c_uint64, c_int, _P],
 }
 
 _lib = None

@@ -167,25 +167,26 @@ class _SoftStepFn(torch.autograd.Function):
     """(x_next, soft_copy_flag) = soft reverse step(logits, x_soft); noise is recomputed in the backward."""
 
     @staticmethod
-    def forward(ctx, logits, x_soft, mc_t, mc_s, temp, cft, seed, step, sample_offset, uniforms):
+    def forward(ctx, logits, x_soft, mc_t, mc_s, temp, cft, seed, step, sample_offset, uniforms, mc_rows=None):
         logits, x_soft = logits.contiguous(), x_soft.contiguous()
-        x_next, flag = ops.reverse_step_soft_fwd(logits, x_soft, mc_t, mc_s, temp, cft, seed, step, sample_offset, uniforms)
+        x_next, flag = ops.reverse_step_soft_fwd(logits, x_soft, mc_t, mc_s, temp, cft, seed, step, sample_offset, uniforms,
+                                                 mc_rows)
         ctx.save_for_backward(logits, x_soft)
-        ctx.consts = (mc_t, mc_s, temp, cft, seed, step, sample_offset, uniforms)
+        ctx.consts = (mc_t, mc_s, temp, cft, seed, step, sample_offset, uniforms, mc_rows)
         return x_next, flag.unsqueeze(-1)
 
     @staticmethod
     def backward(ctx, g_next, g_flag):
         logits, x_soft = ctx.saved_tensors
-        mc_t, mc_s, temp, cft, seed, step, sample_offset, uniforms = ctx.consts
+        mc_t, mc_s, temp, cft, seed, step, sample_offset, uniforms, mc_rows = ctx.consts
         gf = g_flag.reshape(g_flag.shape[0], g_flag.shape[1]).contiguous() if g_flag is not None else None
         dlogits, dx = ops.reverse_step_soft_bwd(logits, x_soft, g_next.contiguous(), gf, mc_t, mc_s, temp, cft, seed, step,
-                                                sample_offset, uniforms)
-        return dlogits, dx, None, None, None, None, None, None, None, None
+                                                sample_offset, uniforms, mc_rows)
+        return dlogits, dx, None, None, None, None, None, None, None, None, None
 
 
-def soft_step_with_grad(logits, x_soft, mc_t, mc_s, temp, cft, seed, step, sample_offset, uniforms):
-    return _SoftStepFn.apply(logits, x_soft, mc_t, mc_s, temp, cft, seed, step, sample_offset, uniforms)
+def soft_step_with_grad(logits, x_soft, mc_t, mc_s, temp, cft, seed, step, sample_offset, uniforms, mc_rows=None):
+    return _SoftStepFn.apply(logits, x_soft, mc_t, mc_s, temp, cft, seed, step, sample_offset, uniforms, mc_rows)
 
 
 class _KLStepFn(torch.autograd.Function):

@@ -41,7 +41,7 @@
 #include "drk_common.h"
 #include "../../include/drakes_hip.h"
 
-#include <stdlib.h>
+#include <atomic>
 
 typedef __bf16 bf16v8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16v4 __attribute__((ext_vector_type(4)));
@@ -809,8 +809,9 @@ extern "C" int drk_sample_bf16(const void* wstream, const void* stem_w, const vo
                                const float* mc_table, const float* uniforms, const int64_t* x_init, int64_t* x_out,
                                signed char* traj_out, float* logits_out, int dump_fwd, float* dbg_feat, int dbg_layer, int B, int L, int num_steps, int n_layers,
                                const int* dilations, int noise_removal, uint64_t seed, uint64_t sample_offset,
-                               void* stream) {
+                               int flags, void* stream) {
   if (B < 0 || L <= 0) return drk_set_error_msg(DRK_EINVAL, "drk_sample_bf16: bad shape");
+  if (flags & ~DRK_SAMPLE_GENERIC) return drk_set_error_msg(DRK_EINVAL, "drk_sample_bf16: unknown flag");
   if (B == 0) return DRK_OK;
   if (L > MAXPOS) return drk_set_error_msg(DRK_EINVAL, "drk_sample_bf16: L > 224 is not supported by the fused loop");
   if (n_layers < 1 || n_layers > MAX_LAYERS || num_steps < 0 || (num_steps == 0 && !noise_removal))
@@ -829,11 +830,18 @@ extern "C" int drk_sample_bf16(const void* wstream, const void* stem_w, const vo
   }
   bool fast = (L > 192 && L <= 208);   // the all-immediate-addressing build (see sample_body)
   for (int i = 0; i < n_layers; ++i) fast = fast && ((dilations[i] >= 1 && dilations[i] <= 4) || dilations[i] == 16 || dilations[i] == 64);
-  if (getenv("DRK_SAMPLE_GENERIC")) fast = false;   // tests: the generic build must give the same bits
-  const void* kern = fast ? (const void*)k_sample_bf16<true> : (const void*)k_sample_bf16<false>;
-  {  // per device, cheap, and not an allocation: lets the launch ask for more than 64 KB of LDS
-    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    if (e != hipSuccess) return drk_set_error(e, "drk_sample_bf16(hipFuncSetAttribute)");
+  if (flags & DRK_SAMPLE_GENERIC) fast = false;   // tests: the generic build must give the same bits
+  {  // once per (device, build): lets the launch ask for more than 64 KB of LDS.  Not an allocation.
+    static std::atomic<unsigned> lds_set[2][DRK_MAX_DEVICES];
+    int devid = 0;
+    hipError_t e = hipGetDevice(&devid);
+    if (e != hipSuccess) return drk_set_error(e, "drk_sample_bf16(hipGetDevice)");
+    if (devid < 0 || devid >= DRK_MAX_DEVICES || !lds_set[fast][devid].load(std::memory_order_acquire)) {
+      const void* kern = fast ? (const void*)k_sample_bf16<true> : (const void*)k_sample_bf16<false>;
+      e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+      if (e != hipSuccess) return drk_set_error(e, "drk_sample_bf16(hipFuncSetAttribute)");
+      if (devid >= 0 && devid < DRK_MAX_DEVICES) lds_set[fast][devid].store(1u, std::memory_order_release);
+    }
   }
   if (fast)
     hipLaunchKernelGGL(k_sample_bf16<true>, dim3(B), dim3(512), LDS_BYTES, (hipStream_t)stream, a);

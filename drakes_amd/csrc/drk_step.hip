@@ -21,7 +21,7 @@ int drk_set_error_msg(int code, const char* msg) {
   return code;
 }
 extern "C" const char* drk_last_error(void) { return g_err; }
-extern "C" int drk_version(void) { return 100; }
+extern "C" int drk_version(void) { return DRK_VERSION; }
 
 // ------------------------------------------------------------------------------------ kernels
 __device__ __forceinline__ void load5(const float* __restrict__ p, long i, float v[DRK_V]) {
@@ -71,19 +71,23 @@ template <bool INJECT>
 __global__ void __launch_bounds__(256)
     k_reverse_step_hard(const float* __restrict__ logits, const int64_t* x,  // x_next may alias x
                         const float* __restrict__ uniforms, int64_t* x_next, long n, int L, float mc_t,
-                        float mc_s, uint64_t seed, uint32_t step, uint64_t sample_offset) {
+                        float mc_s, const float* __restrict__ mc_rows, uint64_t seed, uint32_t step,
+                        uint64_t sample_offset) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const int tok = (int)x[i];
     int out = tok;
     if (tok == DRK_MASK) {  // carry-over: an unmasked position keeps its token (:482-486)
       float lg[DRK_V], lp[DRK_V], q[DRK_V], u[DRK_V];
       load5(logits, i, lg);
+      // n < 2^32 on every call the entry point accepts (B, L are ints): 32-bit divide, not the 64-bit one
+      const uint32_t row = (uint32_t)i / (uint32_t)L;
       if (INJECT)
         load5(uniforms, i, u);
-      else {
-        // n < 2^32 on every call the entry point accepts (B, L are ints): 32-bit divide, not the 64-bit one
-        const uint32_t row = (uint32_t)i / (uint32_t)L;
+      else
         drk_step_uniforms(seed, step, sample_offset + row, (uint32_t)i - row * (uint32_t)L, u);
+      if (mc_rows) {   // per-row timesteps (t [B,1] with unequal rows, :462-474)
+        mc_t = mc_rows[2 * row];
+        mc_s = mc_rows[2 * row + 1];
       }
       drk_subs_logp(lg, DRK_MASK, lp);
       drk_posterior(lp, mc_t, mc_s, q);
@@ -113,19 +117,21 @@ __global__ void __launch_bounds__(256) k_denoise_argmax(const float* __restrict_
 // first of the step's Philox uniforms, or uniforms[i] when injected.
 template <bool INJECT>
 __global__ void __launch_bounds__(256) k_q_xt(const int64_t* __restrict__ x0, const float* __restrict__ uniforms,
-                                              int64_t* __restrict__ xt, long n, int L, float move_chance, uint64_t seed,
-                                              uint32_t step, uint64_t sample_offset) {
+                                              int64_t* __restrict__ xt, long n, int L, float move_chance,
+                                              const float* __restrict__ mc_rows, uint64_t seed, uint32_t step,
+                                              uint64_t sample_offset) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     float u;
+    const uint32_t row = (uint32_t)i / (uint32_t)L;
     if (INJECT) {
       u = uniforms[i];
     } else {
       float uu[DRK_V];
-      const uint32_t row = (uint32_t)i / (uint32_t)L;
       drk_step_uniforms(seed, step, sample_offset + row, (uint32_t)i - row * (uint32_t)L, uu);
       u = uu[0];
     }
-    xt[i] = (u < move_chance) ? (int64_t)DRK_MASK : x0[i];
+    const float mc = mc_rows ? mc_rows[row] : move_chance;   // per-row move chance [B] (:425-436 takes [B,1])
+    xt[i] = (u < mc) ? (int64_t)DRK_MASK : x0[i];
   }
 }
 
@@ -284,8 +290,8 @@ extern "C" int drk_subs_fwd(const float* logits, const int64_t* x, const float* 
 }
 
 extern "C" int drk_reverse_step_hard(const float* logits, const int64_t* x, const float* uniforms, int64_t* x_next,
-                                     int B, int L, float mc_t, float mc_s, uint64_t seed, uint32_t step,
-                                     uint64_t sample_offset, void* stream) {
+                                     int B, int L, float mc_t, float mc_s, const float* mc_rows, uint64_t seed,
+                                     uint32_t step, uint64_t sample_offset, void* stream) {
   DRK_SHAPE_GUARD("drk_reverse_step_hard");
   if (!logits || !x || !x_next || B < 0 || L <= 0)
     return drk_set_error_msg(DRK_EINVAL, "drk_reverse_step_hard: bad arguments");
@@ -294,10 +300,10 @@ extern "C" int drk_reverse_step_hard(const float* logits, const int64_t* x, cons
   if (n >= (1L << 32)) return drk_set_error_msg(DRK_EINVAL, "drk_reverse_step_hard: B*L must be below 2^32");
   if (uniforms)
     hipLaunchKernelGGL(k_reverse_step_hard<true>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, logits, x,
-                       uniforms, x_next, n, L, mc_t, mc_s, seed, step, sample_offset);
+                       uniforms, x_next, n, L, mc_t, mc_s, mc_rows, seed, step, sample_offset);
   else
     hipLaunchKernelGGL(k_reverse_step_hard<false>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, logits, x,
-                       uniforms, x_next, n, L, mc_t, mc_s, seed, step, sample_offset);
+                       uniforms, x_next, n, L, mc_t, mc_s, mc_rows, seed, step, sample_offset);
   DRK_CHECK_LAUNCH();
   return DRK_OK;
 }
@@ -314,17 +320,17 @@ extern "C" int drk_denoise_argmax(const float* logits, const int64_t* x, int64_t
 }
 
 extern "C" int drk_q_xt(const int64_t* x0, const float* uniforms, int64_t* xt, int B, int L, float move_chance,
-                        uint64_t seed, uint32_t step, uint64_t sample_offset, void* stream) {
+                        const float* mc_rows, uint64_t seed, uint32_t step, uint64_t sample_offset, void* stream) {
   DRK_SHAPE_GUARD("drk_q_xt");
   if (!x0 || !xt) return drk_set_error_msg(DRK_EINVAL, "drk_q_xt: bad arguments");
   const long n = (long)B * L;
   if (n >= (1L << 32)) return drk_set_error_msg(DRK_EINVAL, "drk_q_xt: B*L must be below 2^32");
   if (uniforms)
     hipLaunchKernelGGL(k_q_xt<true>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x0, uniforms, xt, n, L,
-                       move_chance, seed, step, sample_offset);
+                       move_chance, mc_rows, seed, step, sample_offset);
   else
     hipLaunchKernelGGL(k_q_xt<false>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x0, uniforms, xt, n, L,
-                       move_chance, seed, step, sample_offset);
+                       move_chance, mc_rows, seed, step, sample_offset);
   DRK_CHECK_LAUNCH();
   return DRK_OK;
 }

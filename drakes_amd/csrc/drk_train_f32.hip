@@ -431,7 +431,8 @@ template <bool INJECT>
 __global__ void __launch_bounds__(256)
     k_soft_step_fwd(const float* __restrict__ logits, const float* __restrict__ x_soft, const float* __restrict__ uniforms,
                     float* __restrict__ x_next, float* __restrict__ flag_out, long n, int L, float mc_t, float mc_s,
-                    float inv_temp, float cft, uint64_t seed, uint32_t step, uint64_t sample_offset) {
+                    const float* __restrict__ mc_rows, float inv_temp, float cft, uint64_t seed, uint32_t step,
+                    uint64_t sample_offset) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     float lg[DRK_V], xs[DRK_V], u[DRK_V], lp[DRK_V], y[DRK_V], flag;
     int tok;
@@ -440,12 +441,16 @@ __global__ void __launch_bounds__(256)
       lg[v] = logits[i * DRK_V + v];
       xs[v] = x_soft[i * DRK_V + v];
     }
+    const uint32_t row = (uint32_t)i / (uint32_t)L;   // B*L < 2^32, checked by the entry point
     if (INJECT) {
 #pragma unroll
       for (int v = 0; v < DRK_V; ++v) u[v] = uniforms[i * DRK_V + v];
     } else {
-      const uint32_t row = (uint32_t)i / (uint32_t)L;   // B*L < 2^32, checked by the entry point
       drk_step_uniforms(seed, step, sample_offset + row, (uint32_t)i - row * (uint32_t)L, u);
+    }
+    if (mc_rows) {   // per-row timesteps
+      mc_t = mc_rows[2 * row];
+      mc_s = mc_rows[2 * row + 1];
     }
     soft_row(lg, xs, u, mc_t, mc_s, inv_temp, cft, tok, lp, y, flag);
 #pragma unroll
@@ -460,8 +465,8 @@ template <bool INJECT>
 __global__ void __launch_bounds__(256)
     k_soft_step_bwd(const float* __restrict__ logits, const float* __restrict__ x_soft, const float* __restrict__ uniforms,
                     const float* __restrict__ gnext, const float* __restrict__ gflag, float* __restrict__ dlogits,
-                    float* __restrict__ dx, long n, int L, float mc_t, float mc_s, float inv_temp, float cft, uint64_t seed,
-                    uint32_t step, uint64_t sample_offset) {
+                    float* __restrict__ dx, long n, int L, float mc_t, float mc_s, const float* __restrict__ mc_rows,
+                    float inv_temp, float cft, uint64_t seed, uint32_t step, uint64_t sample_offset) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     float lg[DRK_V], xs[DRK_V], u[DRK_V], lp[DRK_V], y[DRK_V], G[DRK_V], flag;
     int tok;
@@ -471,12 +476,16 @@ __global__ void __launch_bounds__(256)
       xs[v] = x_soft[i * DRK_V + v];
       G[v] = gnext[i * DRK_V + v];
     }
+    const uint32_t row = (uint32_t)i / (uint32_t)L;   // B*L < 2^32, checked by the entry point
     if (INJECT) {
 #pragma unroll
       for (int v = 0; v < DRK_V; ++v) u[v] = uniforms[i * DRK_V + v];
     } else {
-      const uint32_t row = (uint32_t)i / (uint32_t)L;   // B*L < 2^32, checked by the entry point
       drk_step_uniforms(seed, step, sample_offset + row, (uint32_t)i - row * (uint32_t)L, u);
+    }
+    if (mc_rows) {   // per-row timesteps
+      mc_t = mc_rows[2 * row];
+      mc_s = mc_rows[2 * row + 1];
     }
     soft_row(lg, xs, u, mc_t, mc_s, inv_temp, cft, tok, lp, y, flag);
     float dflag = gflag ? gflag[i] : 0.f;
@@ -796,39 +805,42 @@ extern "C" int drk_subs_bwd(const float* logits, const int64_t* x, const float* 
 }
 
 extern "C" int drk_reverse_step_soft_fwd(const float* logits, const float* x_soft, const float* uniforms, float* x_next,
-                                         float* flag, int B, int L, float mc_t, float mc_s, float temp,
-                                         float copy_flag_temp, uint64_t seed, uint32_t step, uint64_t sample_offset,
-                                         void* stream) {
+                                         float* flag, int B, int L, float mc_t, float mc_s, const float* mc_rows,
+                                         float temp, float copy_flag_temp, uint64_t seed, uint32_t step,
+                                         uint64_t sample_offset, void* stream) {
   DRK_SHAPE_GUARD("drk_reverse_step_soft_fwd");
   ARGCHECK(logits && x_soft && x_next && flag && temp > 0.f, "drk_reverse_step_soft_fwd");
   const long n = (long)B * L;
   ARGCHECK(n < (1L << 32), "drk_reverse_step_soft_fwd (B*L must be below 2^32)");
   if (uniforms)
     hipLaunchKernelGGL(k_soft_step_fwd<true>, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, logits, x_soft,
-                       uniforms, x_next, flag, n, L, mc_t, mc_s, 1.0f / temp, copy_flag_temp, seed, step, sample_offset);
+                       uniforms, x_next, flag, n, L, mc_t, mc_s, mc_rows, 1.0f / temp, copy_flag_temp, seed, step,
+                       sample_offset);
   else
     hipLaunchKernelGGL(k_soft_step_fwd<false>, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, logits, x_soft,
-                       uniforms, x_next, flag, n, L, mc_t, mc_s, 1.0f / temp, copy_flag_temp, seed, step, sample_offset);
+                       uniforms, x_next, flag, n, L, mc_t, mc_s, mc_rows, 1.0f / temp, copy_flag_temp, seed, step,
+                       sample_offset);
   DRK_CHECK_LAUNCH();
   return DRK_OK;
 }
 
 extern "C" int drk_reverse_step_soft_bwd(const float* logits, const float* x_soft, const float* uniforms,
                                          const float* grad_x_next, const float* grad_flag, float* dlogits, float* dx, int B,
-                                         int L, float mc_t, float mc_s, float temp, float copy_flag_temp, uint64_t seed,
-                                         uint32_t step, uint64_t sample_offset, void* stream) {
+                                         int L, float mc_t, float mc_s, const float* mc_rows, float temp,
+                                         float copy_flag_temp, uint64_t seed, uint32_t step, uint64_t sample_offset,
+                                         void* stream) {
   DRK_SHAPE_GUARD("drk_reverse_step_soft_bwd");
   ARGCHECK(logits && x_soft && grad_x_next && dlogits && dx && temp > 0.f, "drk_reverse_step_soft_bwd");
   const long n = (long)B * L;
   ARGCHECK(n < (1L << 32), "drk_reverse_step_soft_bwd (B*L must be below 2^32)");
   if (uniforms)
     hipLaunchKernelGGL(k_soft_step_bwd<true>, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, logits, x_soft,
-                       uniforms, grad_x_next, grad_flag, dlogits, dx, n, L, mc_t, mc_s, 1.0f / temp, copy_flag_temp, seed,
-                       step, sample_offset);
+                       uniforms, grad_x_next, grad_flag, dlogits, dx, n, L, mc_t, mc_s, mc_rows, 1.0f / temp, copy_flag_temp,
+                       seed, step, sample_offset);
   else
     hipLaunchKernelGGL(k_soft_step_bwd<false>, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, logits, x_soft,
-                       uniforms, grad_x_next, grad_flag, dlogits, dx, n, L, mc_t, mc_s, 1.0f / temp, copy_flag_temp, seed,
-                       step, sample_offset);
+                       uniforms, grad_x_next, grad_flag, dlogits, dx, n, L, mc_t, mc_s, mc_rows, 1.0f / temp, copy_flag_temp,
+                       seed, step, sample_offset);
   DRK_CHECK_LAUNCH();
   return DRK_OK;
 }

@@ -61,6 +61,15 @@ class Diffusion(nn.Module):
     def dtype(self):
         return torch.float32
 
+    def refresh_weights(self):
+        """Call after writing parameters in a way torch's version counter does not see (`p.data.copy_(...)`,
+        `p.data.mul_(...)` — e.g. the reference's EMA `copy_to` / `restore`, models/ema.py:62,87): drops the packed
+        weight copies, the bf16 fragment stream, the schedule cache, the captured graph and the logits cache."""
+        self.backbone.invalidate()
+        self._sched_cache = None
+        self._graph = None
+        self._soft_logits_cache = {}
+
     # ------------------------------------------------------------------ forward
     def _process_sigma(self, sigma):
         """reference :255-264"""
@@ -101,7 +110,8 @@ class Diffusion(nn.Module):
         return self.backbone.time_bias(s)
 
     def _ddpm_update(self, x, t, dt, return_process=False, *, seed=None, step=0, sample_offset=0, uniforms=None):
-        """One hard reverse step — reference :462-486.  `t` [B,1] (all rows equal, as _sample builds it)."""
+        """One hard reverse step — reference :462-486.  `t` [B,1]; rows may sit at different times (then the kernel
+        reads one (move_chance_t, move_chance_s) pair per row)."""
         sigma_t, _ = self.noise(t)
         sigma_s, _ = self.noise(t - dt)
         if sigma_t.ndim > 1:
@@ -111,13 +121,15 @@ class Diffusion(nn.Module):
         move_chance_t = 1 - torch.exp(-sigma_t)
         move_chance_s = 1 - torch.exp(-sigma_s)
         mc_t, mc_s = float(move_chance_t[0]), float(move_chance_s[0])
+        mc_rows = None
         if not (bool((move_chance_t == move_chance_t[0]).all()) and bool((move_chance_s == move_chance_s[0]).all())):
-            raise NotImplementedError('per-row timesteps: the fused step takes one (mc_t, mc_s) per call')
+            mc_rows = torch.stack([move_chance_t, move_chance_s], dim=-1).to(device=x.device, dtype=torch.float32).contiguous()
         if seed is None and uniforms is None:
             seed = self._draw_seed()
         with torch.no_grad():
-            logits = self.backbone(x, self._process_sigma(sigma_t))
-            x_next = ops.reverse_step_hard(logits, x.contiguous(), mc_t, mc_s, seed or 0, step, sample_offset, uniforms)
+            logits = self.backbone(x, self._process_sigma(sigma_t).to(x.device))
+            x_next = ops.reverse_step_hard(logits, x.contiguous(), mc_t, mc_s, seed or 0, step, sample_offset, uniforms,
+                                           mc_rows=mc_rows)
         if return_process:
             copy_flag = (x != self.mask_index).to(x.dtype)
             return x_next, x, sigma_t, move_chance_t[:, None, None], copy_flag
@@ -180,25 +192,28 @@ class Diffusion(nn.Module):
         num_steps = len(table)
         dev = x.device
         mc = torch.tensor([[row[2], row[3]] for row in table], dtype=torch.float32, device=dev)
-        key = (B, L, num_steps, shared.data_ptr(), self.backbone._weights_key(), self.hip_dtype)
+        # the graph owns every buffer it points at: the time bias is COPIED into st['shared'] before each replay, so a
+        # cache hit does not depend on the allocator handing `shared` the same address again
+        key = (B, L, num_steps, tuple(shared.shape), self.backbone._weights_key(), self.hip_dtype)
         st = self._graph
         if st is None or st['key'] != key:
             st = {'key': key, 'x': torch.empty_like(x), 'counter': torch.zeros(1, dtype=torch.int32, device=dev), 'mc': mc,
-                  'rng': torch.zeros(2, dtype=torch.int64, device=dev)}
+                  'rng': torch.zeros(2, dtype=torch.int64, device=dev), 'shared': shared.clone()}
             st['x'].copy_(x)
             work = {}
             self.backbone.packed()
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):          # warm-up outside capture: allocates the work buffers
-                logits = fwd(st['x'], shared, 0, work)
+                logits = fwd(st['x'], st['shared'], 0, work)
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                logits = fwd(st['x'], shared, 0, work)
+                logits = fwd(st['x'], st['shared'], 0, work)
                 ops.reverse_step_hard_table(logits, st['x'], st['mc'], st['counter'], st['rng'], out=st['x'])
             st['graph'], st['work'] = graph, work
             self._graph = st
+        st['shared'].copy_(shared)
         st['x'].copy_(x)
         st['mc'].copy_(mc)
         st['counter'].zero_()
@@ -210,16 +225,15 @@ class Diffusion(nn.Module):
 
     # ------------------------------------------------------------------ likelihood
     def q_xt(self, x, move_chance, *, seed=None, step=0, sample_offset=0, uniforms=None):
-        """Computes the noisy sample xt — reference :425-436.  move_chance: [B,1], all rows equal (as get_likelihood
-        builds it) or a float."""
-        mc = move_chance
+        """Computes the noisy sample xt — reference :425-436.  move_chance: [B,1] (one value per row) or a float."""
+        mc, mc_rows = move_chance, None
         if torch.is_tensor(mc):
-            if not bool((mc == mc.reshape(-1)[0]).all()):
-                raise NotImplementedError('per-row move_chance: the kernel takes one value per call')
+            if mc.numel() > 1 and not bool((mc == mc.reshape(-1)[0]).all()):
+                mc_rows = mc.reshape(-1, 1).to(device=x.device, dtype=torch.float32).contiguous()
             mc = float(mc.reshape(-1)[0])
         if seed is None and uniforms is None:
             seed = self._draw_seed()
-        return ops.q_xt(x.contiguous(), mc, seed or 0, step, sample_offset, uniforms)
+        return ops.q_xt(x.contiguous(), mc, seed or 0, step, sample_offset, uniforms, mc_rows=mc_rows)
 
     @torch.no_grad()
     def get_likelihood(self, x0, num_steps=None, eps=1e-5, n_samples=1, *, seed=None, sample_offset=0, uniforms=None):

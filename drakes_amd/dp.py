@@ -109,10 +109,11 @@ class GradBucket:
                for p, off in zip(self.params, self.offsets)):
             self.attach()
 
-    def allreduce_mean_(self):
-        """Sum over ranks, divide by the world size.  No-op at world size 1."""
+    def allreduce_mean_(self, force=False):
+        """Sum over ranks, divide by the world size.  No-op at world size 1 unless `force` (then the collective runs
+        anyway, when a group exists: the one-GPU test of the RCCL branch)."""
         w = world()
-        if w > 1:
+        if w > 1 or (force and dist.is_initialized()):
             if dist.get_backend() == 'nccl' or self.flat.device.type == 'cpu':
                 dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)          # RCCL ring over xGMI
             else:                       # gloo rehearsal with device tensors (tests): stage on the host

@@ -14,6 +14,8 @@ import torch
 from . import _lib, ops
 
 MAX_L = 224
+SAMPLE_GENERIC = 1        # include/drakes_hip.h: DRK_SAMPLE_GENERIC
+launch_flags = 0          # tests set SAMPLE_GENERIC to compare the two builds of the fused kernel
 
 
 def _frag_tap(m):
@@ -81,9 +83,46 @@ def _launch(bb, tbias, tb_stride, mc, uniforms, x_init, x_out, logits_out, dump_
     P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
     args = (P(pk['wstream']), P(pk['stem_w']), P(pk['head2_w']), P(pk['vecs']), P(tbias), tb_stride, P(mc), P(uniforms), P(x_init), P(x_out),
             P(traj), P(logits_out), dump_fwd, P(dbg_feat), dbg_layer, B, L, num_steps, pk['n_layers'], pk['dil'], 1 if noise_removal else 0, seed,
-            sample_offset, ops._stream())
+            sample_offset, launch_flags, ops._stream())
     flop = 2.0 * B * L * (45 * 128 + pk['n_layers'] * 9 * 128 * 128 + 128 * 128 + 128 * 5) * (num_steps + (1 if noise_removal else 0))
     ops.PROFILE.bracket('k_sample_bf16', flop, lambda: _lib.call('drk_sample_bf16', *args))
+
+
+def _uses_fast_build(bb, L):
+    """Mirror of the entry point's choice (drk_sample_bf16.hip): the specialised build runs for 192 < L <= 208 when every
+    dilation is in {1..4, 16, 64}."""
+    dil = [bb.dilation(i) for i in range(bb.num_layers)]
+    return (192 < L <= 208 and all(1 <= d <= 4 or d in (16, 64) for d in dil) and not (launch_flags & SAMPLE_GENERIC))
+
+
+def executed_flop_fraction(bb, L):
+    """MFMA FLOPs one forward of the fused kernel EXECUTES / the dense algorithmic FLOPs of the reference's forward
+    (what bench.py's roofline numerator counts).  The kernel computes whole 16-position tiles (L=200 -> 208), runs the
+    stem as K = 96 instead of 45 and final_conv.2 as 16 output rows instead of 5, and skips (tile, tap) pairs that only
+    multiply padding: every pair of a tap whose shift is >= L in both builds; in the specialised build also the pairs
+    with all 16 shifted rows outside [0, 208) for dilations 16 and 64 (live_lo / live_hi in drk_sample_bf16.hip)."""
+    n = bb.num_layers
+    ntiles = (L + 15) // 16
+    fast = _uses_fast_build(bb, L)
+    tile_taps = 0
+    for i in range(n):
+        d = bb.dilation(i)
+        for k in range(-4, 5):
+            off = k * d
+            if abs(off) >= L and off != 0:
+                continue                                   # whole tap skipped (both builds)
+            if fast and d in (16, 64):
+                live = sum(1 for T in range(ntiles) if (16 * T + off < 208 if off > 0 else 16 * T + 15 >= -off))
+            else:
+                live = ntiles
+            tile_taps += live
+    mfma = 16 * 16 * 32 * 2                                # FLOPs of one v_mfma_f32_16x16x32_bf16
+    executed = (tile_taps * 4 * 8                          # conv taps: 4 k-steps x 8 channel tiles
+                + ntiles * 3 * 8                           # stem, K = 96
+                + ntiles * 4 * 8                           # final_conv.0
+                + ntiles * 4) * mfma                       # final_conv.2 (one 16-row tile)
+    dense = 2.0 * L * (45 * 128 + n * 9 * 128 * 128 + 128 * 128 + 128 * 5)
+    return executed / dense
 
 
 def sample_bf16(model, x, table, sigma_last, seed, sample_offset, uniforms):

@@ -24,19 +24,22 @@ def _scalars(model, t, dt):
 
 def ddpm_update_finetune_gradient(model, x, t, dt, copy_flag_temp, return_process=False, *, seed=None, step=0,
                                   sample_offset=0, uniforms=None):
-    """One soft reverse step (:552-586).  x: int64 [B,L] or float32 [B,L,5]; t [B,1], all rows equal."""
+    """One soft reverse step (:552-586).  x: int64 [B,L] or float32 [B,L,5]; t [B,1] (rows may differ)."""
     if x.ndim == 2 or x.shape[-1] != model.vocab_size:
         x = F.one_hot(x, num_classes=model.vocab_size).to(torch.float32)
     sigma_t, mct, mcs = _scalars(model, t, dt)
+    mc_rows = None
+    sig = model._process_sigma(sigma_t).to(x.device)
     if not (bool((mct == mct[0]).all()) and bool((mcs == mcs[0]).all())):
-        raise NotImplementedError('per-row timesteps: the fused step takes one (mc_t, mc_s) per call')
+        mc_rows = torch.stack([mct, mcs], dim=-1).to(device=x.device, dtype=torch.float32).contiguous()
+    else:
+        sig = sig[:1]                                  # one shared value (all rows are equal)
     if seed is None and uniforms is None:
         seed = model._draw_seed()
-    sig = model._process_sigma(sigma_t)[:1]            # one shared value (all rows are equal)
     logits = autograd.backbone_with_grad(model.backbone, x, sig)
     x_next, flag = autograd.soft_step_with_grad(logits, x, float(mct[0]), float(mcs[0]),
                                                 float(model.config.finetuning.gumbel_softmax_temp), copy_flag_temp,
-                                                seed or 0, step, sample_offset, uniforms)
+                                                seed or 0, step, sample_offset, uniforms, mc_rows)
     if return_process:
         return x_next, x, sigma_t, mct[:, None, None], flag
     return x_next

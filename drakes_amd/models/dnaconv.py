@@ -62,13 +62,27 @@ class CNNModel(nn.Module):
         self.dropout = nn.Dropout(args.dropout)
         self._packed = None
         self._packed_key = None
+        self._generation = 0            # bumped by invalidate(): part of every weight-cache key
 
     # ------------------------------------------------------------------ packed weights
     def dilation(self, i):
         return DILATIONS[i // self.args.num_cnn_stacks]
 
     def _weights_key(self):
-        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+        """Identity of the current weights for every derived cache (packed() layouts, the bf16 fragment stream,
+        the sampler's schedule cache, the captured hipGraph, the fine-tune loop's logits reuse).  torch bumps
+        `_version` on in-place tensor ops (optimizer steps, load_state_dict) but NOT on writes through `.data`
+        (the reference's EMA helper does exactly that: models/ema.py:62,87 `param.data.copy_`): after such a write call
+        invalidate() (or Diffusion.refresh_weights())."""
+        return (self._generation,) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def invalidate(self):
+        """Drops every kernel-layout copy of the weights; the next forward re-packs from the parameters."""
+        self._generation += 1
+        self._packed = None
+        self._packed_key = None
+        self._stream = None
+        self._stream_key = None
 
     def packed(self):
         """Kernel-layout copies of the weights; rebuilt when any parameter changed in place

@@ -101,11 +101,21 @@ def subs_fwd(logits, x, out=None):
     return out
 
 
-def reverse_step_hard(logits, x, mc_t, mc_s, seed=0, step=0, sample_offset=0, uniforms=None, out=None):
+def _mc_rows(mc_rows, B, width):
+    """Optional per-row move chances: float32 [B, width] on the device (width 2 = (mc_t, mc_s); 1 for q_xt)."""
+    if mc_rows is None:
+        return None
+    if mc_rows.shape != (B, width):
+        raise ValueError(f'mc_rows: expected shape {(B, width)}, got {tuple(mc_rows.shape)}')
+    return _f(mc_rows, 'mc_rows')
+
+
+def reverse_step_hard(logits, x, mc_t, mc_s, seed=0, step=0, sample_offset=0, uniforms=None, out=None, mc_rows=None):
+    """mc_rows: optional float32 [B,2] = (mc_t, mc_s) per row (per-row timesteps); then mc_t / mc_s are ignored."""
     B, L = x.shape
     out = out if out is not None else torch.empty_like(x)
     _lib.call('drk_reverse_step_hard', _f(logits, 'logits'), _i(x, 'x'), _f(uniforms, 'uniforms'), _i(out, 'x_next'),
-              B, L, float(mc_t), float(mc_s), seed, step, sample_offset, _stream())
+              B, L, float(mc_t), float(mc_s), _mc_rows(mc_rows, B, 2), seed, step, sample_offset, _stream())
     return out
 
 
@@ -244,25 +254,25 @@ def subs_bwd(logits, x, dlogp, out=None):
 
 
 def reverse_step_soft_fwd(logits, x_soft, mc_t, mc_s, temp, copy_flag_temp, seed=0, step=0, sample_offset=0,
-                          uniforms=None):
+                          uniforms=None, mc_rows=None):
     B, L, _ = x_soft.shape
     x_next = torch.empty_like(x_soft)
     flag = torch.empty(B, L, dtype=torch.float32, device=x_soft.device)
     _lib.call('drk_reverse_step_soft_fwd', _f(logits, 'logits'), _f(x_soft, 'x_soft'), _f(uniforms, 'uniforms'),
-              _f(x_next, 'x_next'), _f(flag, 'flag'), B, L, float(mc_t), float(mc_s), float(temp),
+              _f(x_next, 'x_next'), _f(flag, 'flag'), B, L, float(mc_t), float(mc_s), _mc_rows(mc_rows, B, 2), float(temp),
               float(copy_flag_temp) if copy_flag_temp is not None else 0.0, seed, step, sample_offset, _stream())
     return x_next, flag
 
 
 def reverse_step_soft_bwd(logits, x_soft, grad_x_next, grad_flag, mc_t, mc_s, temp, copy_flag_temp, seed=0, step=0,
-                          sample_offset=0, uniforms=None):
+                          sample_offset=0, uniforms=None, mc_rows=None):
     B, L, _ = x_soft.shape
     dlogits = torch.empty_like(logits)
     dx = torch.empty_like(x_soft)
     _lib.call('drk_reverse_step_soft_bwd', _f(logits, 'logits'), _f(x_soft, 'x_soft'), _f(uniforms, 'uniforms'),
               _f(grad_x_next, 'grad_x_next'), _f(grad_flag, 'grad_flag'), _f(dlogits, 'dlogits'), _f(dx, 'dx'), B, L,
-              float(mc_t), float(mc_s), float(temp), float(copy_flag_temp) if copy_flag_temp is not None else 0.0, seed,
-              step, sample_offset, _stream())
+              float(mc_t), float(mc_s), _mc_rows(mc_rows, B, 2), float(temp),
+              float(copy_flag_temp) if copy_flag_temp is not None else 0.0, seed, step, sample_offset, _stream())
     return dlogits, dx
 
 
@@ -309,11 +319,12 @@ def kl_step_bwd(logp, logp_old, last_x, flag, grad_kl, mc_t, want_dold, want_dx,
 
 
 # ---- likelihood ----------------------------------------------------------------------------------
-def q_xt(x0, move_chance, seed=0, step=0, sample_offset=0, uniforms=None, out=None):
+def q_xt(x0, move_chance, seed=0, step=0, sample_offset=0, uniforms=None, out=None, mc_rows=None):
+    """mc_rows: optional float32 [B,1] of per-row move chances; then move_chance is ignored."""
     B, L = x0.shape
     xt = out if out is not None else torch.empty_like(x0)
-    _lib.call('drk_q_xt', _i(x0, 'x0'), _f(uniforms, 'uniforms'), _i(xt, 'xt'), B, L, float(move_chance), seed, step,
-              sample_offset, _stream())
+    _lib.call('drk_q_xt', _i(x0, 'x0'), _f(uniforms, 'uniforms'), _i(xt, 'xt'), B, L, float(move_chance),
+              _mc_rows(mc_rows, B, 1), seed, step, sample_offset, _stream())
     return xt
 
 

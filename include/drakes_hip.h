@@ -54,10 +54,12 @@ int drk_subs_fwd(const float* logits, const int64_t* x, const float* x_soft, flo
 
 /* One hard reverse step from raw logits: _subs_parameterization + the tail of _ddpm_update
  * (:478-486) + _sample_categorical (:24-28).  x_next may alias x.  mc_t/mc_s are the step's
- * move chances (all batch rows equal, :527-528). */
+ * move chances when all batch rows sit at the same time (as _sample builds t, :527-528);
+ * mc_rows (optional, device float32 [B][2] = (mc_t, mc_s) per row) overrides them row by row:
+ * _ddpm_update accepts any t [B,1] (:462-474). */
 int drk_reverse_step_hard(const float* logits, const int64_t* x, const float* uniforms, int64_t* x_next,
-                          int B, int L, float mc_t, float mc_s, uint64_t seed, uint32_t step,
-                          uint64_t sample_offset, void* stream);
+                          int B, int L, float mc_t, float mc_s, const float* mc_rows, uint64_t seed,
+                          uint32_t step, uint64_t sample_offset, void* stream);
 
 /* Noise-removal: SUBS, then argmax over the 4 nucleotides — _sample, :541-549. */
 int drk_denoise_argmax(const float* logits, const int64_t* x, int64_t* x_out, int B, int L, void* stream);
@@ -98,9 +100,10 @@ int drk_reverse_step_soft_wide_bwd(const float* logits, const float* x_soft, con
 /* ---- likelihood -------------------------------------------------------------- */
 /* q(x_t | x_0): Diffusion.q_xt, diffusion_gosai_update.py:425-436.  x0, xt int64 [B][L]; a position is masked when its
  * uniform < move_chance.  uniforms: float32 [B][L] (ONE per position, as torch.rand(*x.shape) there) or NULL = the
- * first Philox uniform of (seed, step, sample_offset + row, position). */
-int drk_q_xt(const int64_t* x0, const float* uniforms, int64_t* xt, int B, int L, float move_chance, uint64_t seed,
-             uint32_t step, uint64_t sample_offset, void* stream);
+ * first Philox uniform of (seed, step, sample_offset + row, position).  mc_rows (optional, device float32 [B]): one
+ * move chance per row (the reference takes move_chance [B,1]) instead of the scalar. */
+int drk_q_xt(const int64_t* x0, const float* uniforms, int64_t* xt, int B, int L, float move_chance,
+             const float* mc_rows, uint64_t seed, uint32_t step, uint64_t sample_offset, void* stream);
 /* One time step of Diffusion.get_likelihood, diffusion_gosai_update.py:911-917: acc[b][l] += multiplier *
  * log p(x0[b][l] | x_t) from RAW backbone logits [B][L][5] (SUBS applied inside).  acc float32 [B][L]. */
 int drk_likelihood_accum(const float* logits, const int64_t* x0, const int64_t* xt, float multiplier, float* acc,
@@ -177,15 +180,16 @@ int drk_subs_bwd(const float* logits, const int64_t* x, const float* x_soft, con
  * _sample_categorical_gradient (:30-35).  x_soft, x_next float32 [B][L][5]; flag [B][L] is the soft copy
  * flag (:577-581); copy_flag_temp <= 0 means None.  The backward recomputes the forward row from the
  * same inputs and returns dL/dlogits and the DIRECT part of dL/dx_soft (the part through the
- * denoiser input comes from drk_stem_bwd). */
+ * denoiser input comes from drk_stem_bwd).  mc_rows: optional per-row (mc_t, mc_s), as in
+ * drk_reverse_step_hard. */
 int drk_reverse_step_soft_fwd(const float* logits, const float* x_soft, const float* uniforms, float* x_next,
-                              float* flag, int B, int L, float mc_t, float mc_s, float temp,
+                              float* flag, int B, int L, float mc_t, float mc_s, const float* mc_rows, float temp,
                               float copy_flag_temp, uint64_t seed, uint32_t step, uint64_t sample_offset,
                               void* stream);
 int drk_reverse_step_soft_bwd(const float* logits, const float* x_soft, const float* uniforms,
                               const float* grad_x_next, const float* grad_flag, float* dlogits, float* dx, int B,
-                              int L, float mc_t, float mc_s, float temp, float copy_flag_temp, uint64_t seed,
-                              uint32_t step, uint64_t sample_offset, void* stream);
+                              int L, float mc_t, float mc_s, const float* mc_rows, float temp, float copy_flag_temp,
+                              uint64_t seed, uint32_t step, uint64_t sample_offset, void* stream);
 
 /* ---- fine-tune loss: per-step KL term (caller of the path) ------------------------
  * kl[b] = sum_{l, v<4} flag[b,l] * (-p + p_old + p*(lp - lp_old)) / move_chance_t * last_x[b,l,v], p = exp(lp):
@@ -218,11 +222,14 @@ int drk_kl_step_bwd(const float* logp, const float* logp_old, const float* last_
  *   logits_out NULL or float32 [B][L][5]: raw logits of forward number dump_fwd (tests)
  *   dbg_feat  NULL or float32 [B][L][128]: residual stream of forward dump_fwd after layer
  *             dbg_layer (-1 = after the stem) (tests)
- * num_steps may be 0 with noise_removal=1: one forward + argmax from x_init. */
+ * num_steps may be 0 with noise_removal=1: one forward + argmax from x_init.
+ * flags: 0, or DRK_SAMPLE_GENERIC = run the general build even where the specialised one (192 < L <= 208, dilations in
+ *        {1..4, 16, 64}: immediate addressing, static live ranges) applies; both give the same bits (tests). */
+#define DRK_SAMPLE_GENERIC 1
 int drk_sample_bf16(const void* wstream, const void* stem_w, const void* head2_w, const float* vecs, const float* tbias, long tb_fwd_stride,
                     const float* mc_table, const float* uniforms, const int64_t* x_init, int64_t* x_out,
                     signed char* traj_out, float* logits_out, int dump_fwd, float* dbg_feat, int dbg_layer, int B, int L, int num_steps, int n_layers,
-                    const int* dilations, int noise_removal, uint64_t seed, uint64_t sample_offset, void* stream);
+                    const int* dilations, int noise_removal, uint64_t seed, uint64_t sample_offset, int flags, void* stream);
 
 /* ---- one residual layer per launch, bf16 MFMA (any L; BASELINE.json configs[4]: 1024-bp sequences) ---------------
  * models/dnaconv.py:88-97 for one layer:  feat_out = feat + relu(conv_dilated(h) + bias)   (feat NULL: no residual — the

@@ -44,25 +44,28 @@ def test_fused_forward_logits(gpu_model, dev, det_sd, B, L):
 
 def test_fused_fast_build_equals_generic_build(gpu_model, dev, monkeypatch):
     """192 < L <= 208 runs k_sample_bf16<true> (zero-padded image, immediate addressing, static live ranges, waves 4-7
-    without the +-192 taps); DRK_SAMPLE_GENERIC forces k_sample_bf16<false> on the same input.  Both add the same
-    products in the same order (skipped tiles only ever added zeros): logits and sampled tokens must be bit-identical."""
+    without the +-192 taps); the DRK_SAMPLE_GENERIC flag forces k_sample_bf16<false> on the same input.  Both add the
+    same products in the same order (skipped tiles only ever added zeros): logits and sampled tokens must be bit-identical."""
     gen = np.random.Generator(np.random.PCG64(5))
     for L in (200, 193, 208):
         x = torch.from_numpy(gen.integers(0, 5, (4, L))).to(dev)
-        monkeypatch.delenv('DRK_SAMPLE_GENERIC', raising=False)
+        monkeypatch.setattr(fastpath, 'launch_flags', 0)
         lf, tf = fastpath.backbone_logits_bf16(gpu_model.backbone, x)
-        monkeypatch.setenv('DRK_SAMPLE_GENERIC', '1')
+        monkeypatch.setattr(fastpath, 'launch_flags', fastpath.SAMPLE_GENERIC)
         lg, tg = fastpath.backbone_logits_bf16(gpu_model.backbone, x)
         assert torch.equal(lf, lg) and torch.equal(tf, tg), L
     gpu_model.hip_dtype = 'bf16'
     try:
-        monkeypatch.delenv('DRK_SAMPLE_GENERIC', raising=False)
+        monkeypatch.setattr(fastpath, 'launch_flags', 0)
         a = gpu_model._sample(num_steps=24, eval_sp_size=6, seed=77)
-        monkeypatch.setenv('DRK_SAMPLE_GENERIC', '1')
+        monkeypatch.setattr(fastpath, 'launch_flags', fastpath.SAMPLE_GENERIC)
         b = gpu_model._sample(num_steps=24, eval_sp_size=6, seed=77)
     finally:
         gpu_model.hip_dtype = 'fp32'
     assert torch.equal(a, b)
+    monkeypatch.setattr(fastpath, 'launch_flags', 2)          # an unknown flag is an error, not ignored
+    with pytest.raises(Exception, match='unknown flag'):
+        fastpath.backbone_logits_bf16(gpu_model.backbone, x)
 
 
 @pytest.mark.parametrize('stacks,L', [(1, 200), (1, 100), (2, 208)])
@@ -164,10 +167,11 @@ def test_fused_sample_vs_reference_tokens(gpu_model, dev):
     want = torch.from_numpy(g['tokens'])
     rate = (toks != want).float().mean().item()
     print(f'bf16 fused sampler vs fp32 reference tokens: mismatch rate {rate:.4f}')
-    # bf16 logits flip near-ties and a flip feeds back; this is a sanity bound, not parity
-    assert rate < 0.5
-    # state after 32 steps is still mostly masked in both: compare the unmasked count
-    assert abs(int((toks != 4).sum()) - int((want != 4).sum())) == 0
+    # bf16 logits flip near-ties (a Gumbel race decided by less than the bf16 logit error), and a flip feeds back into
+    # later forwards.  Measured on this fixture: 0.0019 (3 of 1600 tokens); the bar is ~3x the rate measured over the
+    # tests of this file (worst 0.015 at B=4), far below the 0.75 of unrelated samples.  The distribution-level
+    # criterion is test_bf16_sampler_distribution_matches_fp32.
+    assert rate <= 0.02, rate
 
 
 def test_fused_sample_time_conditioned(dev, det_sd):
@@ -178,7 +182,7 @@ def test_fused_sample_time_conditioned(dev, det_sd):
     b = m._sample(eval_sp_size=4, seed=3).cpu()
     rate = (a != b).float().mean().item()
     print('bf16 vs fp32 kernels, time-conditioned, 16 steps: mismatch', rate)
-    assert rate < 0.25
+    assert rate <= 0.03, rate           # measured <= 0.01; unrelated samples differ in 0.75
 
 
 # ---- layer-per-launch bf16 path (drk_layer_bf16): any length ---------------------------------------------------------
@@ -255,7 +259,7 @@ def test_long_sequences_take_the_layer_path(dev, det_sd):
     assert torch.equal(b[1:], part)
     rate = (a != b).float().mean().item()
     print('L=1024, bf16 layer path vs fp32 kernels: token mismatch', rate)
-    assert rate < 0.25
+    assert rate <= 0.03, rate           # measured <= 0.01; unrelated samples differ in 0.75
     m.hip_graph = True                                # the captured step loop replays the same kernels: same tokens
     assert torch.equal(m._sample(eval_sp_size=3, seed=21).cpu(), b)
     assert torch.equal(m._sample(eval_sp_size=3, seed=22).cpu()[1:], m._sample(eval_sp_size=2, seed=22, sample_offset=1).cpu())
@@ -281,3 +285,114 @@ def test_fused_full_size_properties(dev, det_sd):
     assert torch.equal(a[512:], half)
     assert int(a.min()) >= 0 and int(a.max()) <= 3
     assert (a != c).float().mean().item() > 0.5
+
+
+# ---- distribution-level parity of the bf16 sampler ------------------------------------------------
+def _kmer_freq(tokens, k=3):
+    """Frequencies of the 4^k k-mers over all windows of all sequences (the reference's yardstick: k-mer counts +
+    Pearson correlation, /root/reference/drakes_dna/oracle.py count_kmers / eval.ipynb "3-mer Pearson")."""
+    t = tokens.to(torch.int64)
+    idx = torch.zeros(t.shape[0], t.shape[1] - k + 1, dtype=torch.int64, device=t.device)
+    for j in range(k):
+        idx = idx * 4 + t[:, j:t.shape[1] - k + 1 + j]
+    return torch.bincount(idx.flatten(), minlength=4 ** k).double() / idx.numel()
+
+
+def _pearson(a, b):
+    a, b = a - a.mean(), b - b.mean()
+    return float((a * b).sum() / (a.norm() * b.norm()))
+
+
+def test_bf16_sampler_distribution_matches_fp32(dev, det_sd):
+    """Once bit-exactness is gone (bf16 logits), the honest end-to-end criterion is that the bf16 sampler draws from the
+    same DISTRIBUTION as the token-exact fp32 path.  B = 1024, L = 200, 128 steps + noise removal, SAME Philox noise on
+    both paths (so differences come from logit rounding only, not from sampling noise):
+
+      (a) token mismatch rate fp32 vs bf16                          <= 0.02   (a kernel corrupting 5 % of tokens fails)
+      (b) per-position nucleotide marginals [200 x 4], max |diff|   <= 0.02   (sampling noise of two INDEPENDENT B=1024
+          samples would be ~0.03-0.05; the shared noise makes the paths agree far better)
+      (c) 3-mer frequency Pearson r (the reference's metric)        >= 0.999
+      (d) no-feedback flip rate: the bf16 forward evaluated on the fp32 path's OWN recorded states, step by step, so a
+          flip cannot propagate: positions whose outcome differs / positions the step unmasks  <= 0.01; this separates rounding flips
+          (d) from their amplification through later forwards ((a) - (d))."""
+    from drakes_amd import noise_schedule
+    B, L, steps, seed = 1024, 200, 128, 4242
+    m = drakes_amd.Diffusion(drakes_amd.default_config()).to(dev)
+    m.load_state_dict(det_sd)
+    m.eval()
+    # fp32 path, recording the state every step starts from
+    table = noise_schedule.step_table(m.noise, steps, 1e-5)[0].tolist()
+    shared = m._shared_time_bias(0.0)
+    x = torch.full((B, L), 4, dtype=torch.int64, device=dev)
+    states = []
+    with torch.no_grad():
+        for i in range(steps):
+            states.append(x.clone())
+            logits = m.backbone.forward_f32(x, shared, 0, m._work)
+            ops.reverse_step_hard(logits, x, table[i][2], table[i][3], seed, i, 0, out=x)
+        states.append(x.clone())
+        a = ops.denoise_argmax(m.backbone.forward_f32(x, shared, 0, m._work), x)
+    assert torch.equal(a, m._sample(eval_sp_size=B, seed=seed))          # the loop above IS the fp32 _sample
+    m.hip_dtype = 'bf16'
+    b = m._sample(eval_sp_size=B, seed=seed)
+    # (a)
+    rate = (a != b).float().mean().item()
+    # (b)
+    pa = torch.stack([(a == v).float().mean(0) for v in range(4)], -1)
+    pb = torch.stack([(b == v).float().mean(0) for v in range(4)], -1)
+    marg = (pa - pb).abs().max().item()
+    # (c)
+    r3 = _pearson(_kmer_freq(a), _kmer_freq(b))
+    # (d) one bf16 step from each recorded fp32 state (fused kernel: num_steps = 1 from x_init, step index via the
+    # uniforms of that step), compared with the fp32 path's next state on the positions that were masked
+    flips = newly = 0
+    tb = m.backbone.time_bias(torch.zeros(1, device=dev))
+    for i in range(0, steps, 8):
+        mc = torch.tensor([[table[i][2], table[i][3]]], dtype=torch.float32, device=dev)
+        u = ops.step_uniforms(B, L, seed, i, 0, device=dev).reshape(1, B, L, 5)
+        out = torch.empty_like(x)
+        fastpath._launch(m.backbone, tb, 0, mc, u, states[i], out, None, -1, B, L, 1, False, seed, 0)
+        was_masked = states[i] == 4
+        assert torch.equal(out[~was_masked], states[i][~was_masked])       # carry-over
+        flips += int(((out != states[i + 1]) & was_masked).sum())         # a different token, or a different unmask decision
+        newly += int((was_masked & (states[i + 1] != 4)).sum())
+    flip_rate = flips / max(newly, 1)
+    print(f'bf16 vs fp32 at B=1024: token mismatch {rate:.5f}, marginal max|diff| {marg:.4f}, 3-mer Pearson {r3:.6f}, '
+          f'no-feedback flip rate {flip_rate:.5f} ({flips}/{newly})')
+    # measured on MI355X (round 2): 0.0051 / 0.0068 / 0.999976 / 0.0031
+    assert rate <= 0.02, rate
+    assert marg <= 0.02, marg
+    assert r3 >= 0.999, r3
+    assert flip_rate <= 0.01, flip_rate
+    # and the criterion has teeth: 5 % corrupted tokens fail (a)
+    corrupt = b.clone()
+    sel = torch.rand(B, L, device=dev) < 0.05
+    corrupt[sel] = (corrupt[sel] + 1 + torch.randint(0, 3, (int(sel.sum()),), device=dev)) % 4
+    assert (a != corrupt).float().mean().item() > 0.02
+
+
+def test_bf16_layernorm_with_large_stream_mean(dev, det_sd):
+    """the bf16 kernels take the LayerNorm variance in one pass (E[x^2] - mean^2, fp32).  With trained
+    weights the residual stream can carry |mean| >> std; here the stem bias is offset so that |mean| / std ~ 30 at
+    the first LayerNorm and stays large through the stack.  fp32 cancellation then costs ~6e-8 * 900 = 5e-5 relative in
+    the variance, far below a bf16 ulp: the logits must keep the usual bar against the rounding emulation."""
+    sd = {k: v.clone() for k, v in det_sd.items()}
+    gen = np.random.Generator(np.random.PCG64(55))
+    x = torch.from_numpy(gen.integers(0, 5, (3, 200)))
+    with torch.no_grad():
+        _, feats = O.cnn_forward(sd, x, torch.zeros(3), return_feats=True)
+        std0 = float(feats[0].std(dim=1).mean())
+        sd['backbone.linear.bias'] += 60.0 * std0                # every channel shifted: mean moves, std does not
+        _, feats = O.cnn_forward(sd, x, torch.zeros(3), return_feats=True)
+        ratio = float((feats[0].mean(dim=1).abs() / feats[0].std(dim=1)).mean())
+        emu = E.cnn_forward_bf16(sd, x, torch.zeros(3)).numpy()
+    assert ratio > 20, ratio
+    m = drakes_amd.Diffusion(drakes_amd.default_config()).to(dev)
+    m.load_state_dict(sd)
+    fused, _ = fastpath.backbone_logits_bf16(m.backbone, x.to(dev))
+    tbias = m.backbone.time_bias(torch.zeros(1, device=dev))
+    layers = fastpath.forward_bf16_layers(m.backbone, x.to(dev), tbias, 0)
+    for name, got in (('fused', fused), ('layers', layers)):
+        got = got.cpu().numpy()
+        print(f'|mean|/std = {ratio:.1f}: {name} max|kernel-emulation| = {np.abs(got - emu).max():.2e}')
+        assert np.abs(got - emu).max() < 6e-2 and np.sqrt(((got - emu) ** 2).mean()) < 1e-2

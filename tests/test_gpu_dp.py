@@ -42,3 +42,18 @@ def test_fine_tune_world2_matches_world1(tmp_path):
     assert abs(two[0]['ft_norm'] - one['ft_norm']) <= 1e-3 * one['ft_norm']
     mean_two = 0.5 * (two[0]['ft_losses'] + two[1]['ft_losses'])
     assert torch.allclose(mean_two, one['ft_losses'], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.timeout(300)
+def test_rccl_world1_allreduce_of_grad_bucket():
+    """The 'nccl' (RCCL) branches of dp.py, which every other DP test replaces by gloo: one rank, one GPU."""
+    import os
+    import subprocess
+    import sys
+    from dp_launch import HERE, free_port
+    env = dict(os.environ, RANK='0', LOCAL_RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(free_port()),
+               HSA_ENABLE_IPC_MODE_LEGACY='0', PYTHONUNBUFFERED='1')
+    p = subprocess.run([sys.executable, os.path.join(HERE, 'rccl_world1.py')], env=env, capture_output=True, timeout=240)
+    out = p.stdout.decode(errors='replace') + p.stderr.decode(errors='replace')
+    assert p.returncode == 0, out[-3000:]
+    assert 'RCCL world-1 ok ranks_seen=1' in out

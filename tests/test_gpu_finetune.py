@@ -53,6 +53,30 @@ def test_soft_step_forward_backward(dev, cft):
         assert float(lg.grad[1].abs().max()) == 0.0          # rows holding a token: no gradient into the logits
 
 
+def test_soft_step_per_row_timesteps(dev):
+    """_ddpm_update_finetune_gradient with rows at different times (reference :552-586 takes any t [B,1]): the kernels
+    read one (mc_t, mc_s) pair per row; forward and backward against oracle autograd."""
+    gen = np.random.Generator(np.random.PCG64(23))
+    B, L, temp = 4, 200, 1.0
+    logits = torch.from_numpy((gen.standard_normal((B, L, 5)) * 2).astype(np.float32))
+    x = torch.from_numpy(gen.dirichlet(np.ones(5) * 0.4, (B, L)).astype(np.float32))
+    u = torch.from_numpy(philox.step_uniforms(3, 9, B, L))
+    t = torch.tensor([0.95, 0.6, 0.3, 0.05]).reshape(B, 1)
+    dt = (1 - 1e-5) / 128
+    mc_t = 1 - torch.exp(-O.total_noise(t).squeeze(-1))
+    mc_s = 1 - torch.exp(-O.total_noise(t - dt).squeeze(-1))
+    G = torch.from_numpy(gen.standard_normal((B, L, 5)).astype(np.float32))
+    lo, xo = logits.clone().requires_grad_(), x.clone().requires_grad_()
+    xn, fl = O.soft_step_from_logp(O.subs_parameterization(lo, xo), xo, u, mc_t[:, None, None], mc_s[:, None, None], temp, None)
+    (xn * G).sum().backward()
+    lg, xg = logits.to(dev).requires_grad_(), x.to(dev).requires_grad_()
+    rows = torch.stack([mc_t, mc_s], -1).contiguous().to(dev)
+    xn2, fl2 = autograd.soft_step_with_grad(lg, xg, 0.0, 0.0, temp, None, 3, 9, 0, None, rows)
+    (xn2 * G.to(dev)).sum().backward()
+    np.testing.assert_allclose(xn2.detach().cpu().numpy(), xn.detach().numpy(), rtol=1e-4, atol=2e-6)
+    assert relerr(lg.grad.cpu(), lo.grad) < 1e-4 and relerr(xg.grad.cpu(), xo.grad) < 1e-4
+
+
 def _oracle_grads(sd, fn):
     sdg = {k: v.clone().requires_grad_(k != 'backbone.time_embedder.0.W') for k, v in sd.items()}
     loss = fn(sdg)

@@ -1,9 +1,9 @@
 """End-to-end `_sample` on the GPU against tokens captured from the reference.
 
 At the step boundary tokens are bit-exact (test_gpu_step.py).  End to end the fp32 logits differ
-from the CPU reference in the last bits (different accumulation order), and argmax(q/g) can flip
-on a near-tie; a flipped token then changes every later forward.  We therefore report the
-mismatch rate and require it to be tiny (0 expected on these fixtures)."""
+from the CPU reference in the last bits (different accumulation order), so argmax(q/g) could in
+principle flip on a tie closer than ~1e-6; none does on these fixtures, and the tests demand
+EXACT equality with the reference's tokens."""
 import numpy as np
 import pytest
 import torch
@@ -35,7 +35,7 @@ def test_sample_full_golden(gpu_model, dev):
     rows = (toks != want).any(1).sum().item()
     print(f'mismatch rate full: {rate} ({rows}/8 sequences touched)')
     assert toks.min() >= 0 and toks.max() <= 3
-    assert rate <= 0.02, rate
+    assert rate == 0.0, rate
     # injected uniforms give the same tokens as the in-kernel generator
     toks2 = gpu_model._sample(eval_sp_size=8, seed=123,
                               uniforms=lambda i: ops.step_uniforms(8, 200, seed, i, 0, device=dev)).cpu()
@@ -49,7 +49,7 @@ def test_sample_time_conditioned_golden(dev, det_sd):
     toks = m._sample(eval_sp_size=4, seed=int(g['useed'])).cpu()
     rate = (toks != torch.from_numpy(g['tokens'])).float().mean().item()
     print('mismatch rate tc:', rate)
-    assert rate <= 0.02, rate
+    assert rate == 0.0, rate
 
 
 def test_sample_shard_invariance(gpu_model):
@@ -91,6 +91,38 @@ def test_sample_hip_graph_matches_plain_loop(gpu_model):
             got = gpu_model._sample(eval_sp_size=6, seed=seed, sample_offset=off)
             assert torch.equal(got, want)
         assert gpu_model._graph is not None
+        # the graph owns its time-bias buffer: a second call hits the cache whatever address the fresh bias got
+        g0 = gpu_model._graph['graph']
+        junk = torch.empty(4096, device=want.device)        # perturb the allocator
+        assert torch.equal(gpu_model._sample(eval_sp_size=6, seed=5), gpu_model._sample(eval_sp_size=6, seed=5))
+        assert gpu_model._graph['graph'] is g0
+        del junk
     finally:
         gpu_model.hip_graph = False
         gpu_model._graph = None
+
+
+def test_data_writes_need_refresh_weights(dev, det_sd):
+    """a write through `.data` (the reference's EMA copy_to / restore, models/ema.py:62,87) does not bump
+    torch's version counter, so the packed weight copies cannot notice it; Diffusion.refresh_weights() drops them.
+    load_state_dict and optimizer steps are seen without it."""
+    from drakes_amd import fastpath
+    m = drakes_amd.Diffusion(drakes_amd.default_config(steps=4)).to(dev)
+    m.load_state_dict(det_sd)
+    x = torch.randint(0, 5, (2, 200), device=dev)
+    sig = torch.zeros(2, device=dev)
+    with torch.no_grad():
+        a = m.backbone(x, sig).clone()
+        a16 = fastpath.backbone_logits_bf16(m.backbone, x)[0].clone()
+        m.backbone.final_conv[2].weight.data.mul_(2.0)
+        m.backbone.convs[3].weight.data.mul_(0.5)
+        m.refresh_weights()
+        b = m.backbone(x, sig)
+        b16 = fastpath.backbone_logits_bf16(m.backbone, x)[0]
+    assert (a - b).abs().max().item() > 1e-2 and (a16 - b16).abs().max().item() > 1e-2
+    with torch.no_grad():                                   # in-place ops on the parameter itself are versioned
+        m.backbone.final_conv[2].weight.mul_(0.5)
+        m.backbone.convs[3].weight.mul_(2.0)
+        c = m.backbone(x, sig)
+        c16 = fastpath.backbone_logits_bf16(m.backbone, x)[0]
+    assert (a - c).abs().max().item() < 1e-4 and torch.equal(a16, c16)

@@ -89,3 +89,48 @@ def test_denoise_argmax(dev):
     got = ops.denoise_argmax(logits.to(dev), x.to(dev)).cpu()
     assert torch.equal(got, want)
     assert int(got.max()) <= 3
+
+
+def test_hard_step_per_row_timesteps(dev, gpu_model):
+    """_ddpm_update accepts any t [B,1] (diffusion_gosai_update.py:462-486): rows at different times get their own
+    (move_chance_t, move_chance_s).  Kernel vs oracle (bit-exact), then the method itself."""
+    gen = np.random.Generator(np.random.PCG64(91))
+    B, L = 7, 200
+    logits = torch.from_numpy((gen.standard_normal((B, L, 5)) * 3).astype(np.float32))
+    x = torch.from_numpy(gen.integers(0, 5, (B, L)))
+    x[:, ::2] = 4
+    t = torch.tensor([1.0, 0.9, 0.61, 0.5, 0.33, 0.1, 0.02]).reshape(B, 1)
+    dt = (1 - 1e-5) / 128
+    mc_t = 1 - torch.exp(-O.total_noise(t).squeeze(-1))
+    mc_s = 1 - torch.exp(-O.total_noise(t - dt).squeeze(-1))
+    u = torch.from_numpy(philox.step_uniforms(5, 9, B, L))
+    want = O.hard_step_from_logits(logits, x, u, mc_t[:, None, None], mc_s[:, None, None])
+    rows = torch.stack([mc_t, mc_s], -1).contiguous().to(dev)
+    for inj in (None, u.to(dev)):
+        got = ops.reverse_step_hard(logits.to(dev), x.to(dev), 0.0, 0.0, 5, 9, 0, inj, mc_rows=rows).cpu()
+        assert torch.equal(got, want)
+    # all rows equal through mc_rows == the scalar form
+    same = torch.tensor([[0.5, 0.4]] * B, device=dev)
+    assert torch.equal(ops.reverse_step_hard(logits.to(dev), x.to(dev), 0.0, 0.0, 5, 9, 0, mc_rows=same),
+                       ops.reverse_step_hard(logits.to(dev), x.to(dev), 0.5, 0.4, 5, 9, 0))
+    # the drop-in method: mixed t, time conditioning off -> logits from the model, step vs oracle on those logits
+    xd = x.to(dev)
+    got = gpu_model._ddpm_update(xd, t.to(dev), dt, seed=5, step=9).cpu()
+    with torch.no_grad():
+        lg = gpu_model.backbone(xd, torch.zeros(B, device=dev)).cpu()
+    assert torch.equal(got, O.hard_step_from_logits(lg, x, u, mc_t[:, None, None], mc_s[:, None, None]))
+    with pytest.raises(ValueError):
+        ops.reverse_step_hard(logits.to(dev), x.to(dev), 0.5, 0.4, mc_rows=rows[:3])
+
+
+def test_q_xt_per_row_move_chance(dev, gpu_model):
+    gen = np.random.Generator(np.random.PCG64(92))
+    B, L = 5, 200
+    x0 = torch.from_numpy(gen.integers(0, 4, (B, L)))
+    mc = torch.tensor([0.05, 0.3, 0.5, 0.77, 0.999]).reshape(B, 1)
+    u = torch.from_numpy(philox.step_uniforms(12, 3, B, L)[:, :, 0].copy())
+    want = O.q_xt(x0, mc, u)
+    got = gpu_model.q_xt(x0.to(dev), mc.to(dev), seed=12, step=3).cpu()
+    assert torch.equal(got, want)
+    got_inj = gpu_model.q_xt(x0.to(dev), mc.to(dev), uniforms=u.to(dev)).cpu()
+    assert torch.equal(got_inj, want)

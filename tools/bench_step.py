@@ -61,11 +61,11 @@ def main():
 
     cases = [
         ('reverse_step_hard, Philox in-kernel, all masked', 36,
-         lambda: _lib.call('drk_reverse_step_hard', P(logits), P(x_mask), None, P(out_tok), B, L, mc_t, mc_s, 7, 3, 0, s)),
+         lambda: _lib.call('drk_reverse_step_hard', P(logits), P(x_mask), None, P(out_tok), B, L, mc_t, mc_s, None, 7, 3, 0, s)),
         ('reverse_step_hard, Philox in-kernel, half masked', 36,
-         lambda: _lib.call('drk_reverse_step_hard', P(logits), P(x_half), None, P(out_tok), B, L, mc_t, mc_s, 7, 3, 0, s)),
+         lambda: _lib.call('drk_reverse_step_hard', P(logits), P(x_half), None, P(out_tok), B, L, mc_t, mc_s, None, 7, 3, 0, s)),
         ('reverse_step_hard, injected uniforms, all masked', 56,
-         lambda: _lib.call('drk_reverse_step_hard', P(logits), P(x_mask), P(u), P(out_tok), B, L, mc_t, mc_s, 7, 3, 0, s)),
+         lambda: _lib.call('drk_reverse_step_hard', P(logits), P(x_mask), P(u), P(out_tok), B, L, mc_t, mc_s, None, 7, 3, 0, s)),
         ('subs_fwd (tokens)', 48,
          lambda: _lib.call('drk_subs_fwd', P(logits), P(x_half), None, P(o5a), B, L, s)),
         ('denoise_argmax', 36,
@@ -74,10 +74,10 @@ def main():
          lambda: _lib.call('drk_step_uniforms', P(o5a), B, L, 7, 3, 0, s)),
         ('reverse_step_soft_fwd, Philox in-kernel', 20 + 20 + 20 + 4,
          lambda: _lib.call('drk_reverse_step_soft_fwd', P(logits), P(x_soft), None, P(o5a), P(flag), B, L, mc_t, mc_s,
-                           1.0, 0.0, 7, 3, 0, s)),
+                           None, 1.0, 0.0, 7, 3, 0, s)),
         ('reverse_step_soft_bwd, Philox in-kernel', 20 + 20 + 20 + 4 + 20 + 20,
          lambda: _lib.call('drk_reverse_step_soft_bwd', P(logits), P(x_soft), None, P(u), P(gflag), P(o5a), P(o5b), B, L,
-                           mc_t, mc_s, 1.0, 0.0, 7, 3, 0, s)),
+                           mc_t, mc_s, None, 1.0, 0.0, 7, 3, 0, s)),
     ]
     rows = []
     for name, bpp, fn in cases:
@@ -89,7 +89,7 @@ def main():
               flush=True)
     # the in-sampler cost at B=1024 (launch-bound): same kernel, 204 800 positions
     Bs = 1024
-    med, _ = timed(lambda: _lib.call('drk_reverse_step_hard', P(logits), P(x_mask), None, P(out_tok), Bs, L, mc_t, mc_s, 7,
+    med, _ = timed(lambda: _lib.call('drk_reverse_step_hard', P(logits), P(x_mask), None, P(out_tok), Bs, L, mc_t, mc_s, None, 7,
                                      3, 0, s), 50)
     print(f'in-sampler size B=1024: {med * 1e3:.1f} us per step ({Bs * L * 36 / (med * 1e-3) / 1e9:.0f} GB/s)', flush=True)
     rows.append({'kernel': 'reverse_step_hard at B=1024 (launch-bound)', 'positions': Bs * L, 'median_ms': med})
