@@ -38,7 +38,7 @@ SIGNATURES = {
     'drk_relu_bwd': [_P, _P, _P, c_long, _P],
     'drk_colsum128': [_P, _P, c_long, c_long, _P],
     'drk_ln_bwd': [_P, _P, _P, c_long, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P],
-    'drk_conv_wgrad_f32': [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P],
+    'drk_conv_wgrad_f32': [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, c_long, _P],
     'drk_head_out_bwd': [_P, _P, _P, _P, _P, _P, c_int, c_int, _P],
     'drk_stem_bwd': [_P, _P, _P, _P, _P, _P, c_int, c_int, _P],
     'drk_time_bwd': [_P, _P, c_int, _P, _P, _P, c_int, _P, _P, _P, _P, _P],
@@ -54,6 +54,10 @@ SIGNATURES = {
     'drk_ln_fwd_bf16': [_P, _P, c_long, _P, _P, _P, c_int, c_int, _P],
     'drk_sample_bf16': [_P, _P, _P, _P, _P, c_long, _P, _P, _P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, c_int,
                         c_uint64, c_uint64, c_int, _P],
+}
+
+HOST_QUERIES = {
+    'drk_conv_wgrad_workspace_bytes': [c_int, c_int, c_int],
 }
 
 _lib = None
@@ -77,6 +81,10 @@ def load():
     lib.drk_version.argtypes = []
     lib.drk_last_error.restype = c_char_p
     lib.drk_last_error.argtypes = []
+    for name, argtypes in HOST_QUERIES.items():       # host-side size queries: return a byte count, launch nothing
+        fn = getattr(lib, name)
+        fn.restype = c_long
+        fn.argtypes = argtypes
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype = c_int

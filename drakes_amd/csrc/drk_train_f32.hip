@@ -121,13 +121,14 @@ __global__ void __launch_bounds__(256) k_ln_bwd(const float* __restrict__ dh, co
 // ------------------------------------------------------------------------------------ conv weight gradient
 // dwt[t][ci][co] += sum_rows h[row + off_t][ci] * dc[row][co]     (rows whose shifted position leaves [0,L) add 0)
 // GEMM with K = rows on the f32-input MFMA: A = h^T [32 ci x 2 rows], B = dc [2 rows x 32 co]; both operands are
-// row-contiguous, so every wave-load is two dense 128-byte spans.  Workgroup = (row chunk, tap); wave w = ci tile w,
-// all four co tiles.  Partial 128x128 tiles are added with fp32 atomics, 32 consecutive co per half-wave.
-// Weight gradient of one tap: dW_t[ci][co] = sum_rows h[row + off][ci] * dc[row][co].  Grid = (row chunks, taps); a
-// workgroup reduces `wg_rows` rows with f32 MFMAs (K = 2 rows per instruction) and adds its 128x128 partial with fp32
-// atomics.  wg_rows is chosen by the host so that small batches still fill the chip.
+// row-contiguous, so every wave-load is two dense 128-byte spans.  Grid = (row chunks, taps); wave w = ci tile w, all
+// four co tiles; a workgroup reduces `wg_rows` rows (chosen by the host so that small batches still fill the chip).
+// DETERMINISTIC split-K: the workgroup STORES its 128x128 partial into slab (chunk, tap) of the caller's workspace
+// (plain 128-byte row segments), and k_wgrad_reduce adds the slabs in chunk order: the same bits on every run, and
+// plain stores move at 4-5x the rate of float atomics (MI355X_MICROARCH.md, Global float atomics).
+#define WG_SLAB (DRK_C * DRK_C)   // floats per (chunk, tap) slab
 __global__ void __launch_bounds__(256) k_conv_wgrad(const float* __restrict__ h, const float* __restrict__ dc,
-                                                    float* __restrict__ dwt, float* __restrict__ dbias, long M, int L, int taps, int dil,
+                                                    float* __restrict__ slabs, float* __restrict__ bslabs, long M, int L, int taps, int dil,
                                                     int wg_rows) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int half = lane >> 5, lr = lane & 31;
@@ -162,7 +163,7 @@ __global__ void __launch_bounds__(256) k_conv_wgrad(const float* __restrict__ h,
   float a0, a1, a2, a3;
   f32x4 b0, b1, b2, b3;
   f32x4 bsum = {0.f, 0.f, 0.f, 0.f};   // column sums of dc = the conv bias gradient (one wave of the centre-tap workgroup)
-  const bool do_bias = dbias && off == 0 && t == taps / 2 && w == 0;
+  const bool do_bias = bslabs && off == 0 && t == taps / 2 && w == 0;
   fetch(0, a0, b0);
   fetch(1, a1, b1);
   fetch(2, a2, b2);
@@ -188,17 +189,28 @@ __global__ void __launch_bounds__(256) k_conv_wgrad(const float* __restrict__ h,
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float v = bsum[j] + __shfl_xor(bsum[j], 32);      // even + odd rows
-      if (half == 0) atomicAdd(dbias + 32 * j + lr, v);
+      if (half == 0) bslabs[(long)blockIdx.x * DRK_C + 32 * j + lr] = v;
     }
   }
-  float* dst = dwt + (long)t * DRK_C * DRK_C;
+  float* dst = slabs + ((long)blockIdx.x * taps + t) * WG_SLAB;
 #pragma unroll
   for (int j = 0; j < 4; ++j)
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int ci = 32 * w + (i & 3) + 8 * (i >> 2) + 4 * half;
-      atomicAdd(dst + ci * DRK_C + 32 * j + lr, acc[j][i]);
+      dst[ci * DRK_C + 32 * j + lr] = acc[j][i];
     }
+}
+
+// out[i] += slabs[0][i] + slabs[1][i] + ... (fixed order), i < n (n % 4 == 0); slab s starts at slabs + s * stride.
+// One f32x4 per lane, consecutive lanes on consecutive 16-byte pieces: every wave-load is a dense 1-KiB span.
+__global__ void __launch_bounds__(256) k_slab_reduce(const float* __restrict__ slabs, int n_slabs, long stride,
+                                                     float* __restrict__ out, long n4) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    f32x4 s = ((const f32x4*)slabs)[i];
+    for (int k = 1; k < n_slabs; ++k) s += ((const f32x4*)(slabs + k * stride))[i];
+    ((f32x4*)out)[i] += s;
+  }
 }
 
 // ------------------------------------------------------------------------------------ head (128 -> 5) backward
@@ -741,18 +753,54 @@ extern "C" int drk_ln_bwd(const float* dh, const float* feat, const float* tbias
   return DRK_OK;
 }
 
-extern "C" int drk_conv_wgrad_f32(const float* h, const float* dc, float* dwt, float* dbias, int B, int L, int taps,
-                                  int dilation, void* stream) {
-  DRK_SHAPE_GUARD("drk_conv_wgrad_f32");
-  ARGCHECK(h && dc && dwt && taps >= 1 && (taps & 1) && dilation >= 0, "drk_conv_wgrad_f32");
-  const long M = (long)B * L;
-  // >= ~2 workgroups per CU when the batch allows it; fewer rows per workgroup cost more atomics (64 KB each)
-  int wg_rows = 512;
-  while (wg_rows > 64 && ((M + wg_rows - 1) / wg_rows) * taps < 512) wg_rows >>= 1;
-  hipLaunchKernelGGL(k_conv_wgrad, dim3((unsigned)((M + wg_rows - 1) / wg_rows), (unsigned)taps), dim3(256), 0,
-                     (hipStream_t)stream, h, dc, dwt, dbias, M, L, taps, dilation, wg_rows);
+// Row chunk of the split-K weight gradient: the smallest 64 * 2^k rows with at most WG_MAX_SLABS (chunk, tap)
+// workgroups — two co-resident workgroups per CU (the loop is load-latency-bound: a second workgroup hides it; one
+// round of 1024-row workgroups measured 27 % slower at B = 128), and a bounded workspace (one 64-KB slab each).
+#define WG_MAX_SLABS 504
+#define WG_MAX_TAPS 9
+static int wgrad_rows_per_chunk(long M, int taps) {
+  long wg_rows = 64;
+  while (((M + wg_rows - 1) / wg_rows) * taps > WG_MAX_SLABS) wg_rows <<= 1;
+  return (int)wg_rows;
+}
+static long wgrad_ws_floats(long M, int taps) {
+  const long chunks = (M + wgrad_rows_per_chunk(M, taps) - 1) / wgrad_rows_per_chunk(M, taps);
+  return chunks * ((long)taps * WG_SLAB + DRK_C);
+}
+
+extern "C" long drk_conv_wgrad_workspace_bytes(int B, int L, int taps) {
+  if (B <= 0 || L <= 0 || taps < 1 || taps > WG_MAX_TAPS) return 0;
+  return wgrad_ws_floats((long)B * L, taps) * (long)sizeof(float);
+}
+
+// Shared by the workspace form and the allocation-free form: slabs in `ws` (chunks x taps x 128 x 128 floats, then
+// chunks x 128 bias partials), then the ordered reduction into dwt / dbias.
+static int wgrad_launch(const float* h, const float* dc, float* dwt, float* dbias, long M, int L, int taps, int dilation,
+                        float* ws, hipStream_t stream) {
+  const int wg_rows = wgrad_rows_per_chunk(M, taps);
+  const long chunks = (M + wg_rows - 1) / wg_rows;
+  float* bslabs = ws + chunks * taps * WG_SLAB;
+  hipLaunchKernelGGL(k_conv_wgrad, dim3((unsigned)chunks, (unsigned)taps), dim3(256), 0, stream, h, dc, ws,
+                     dbias ? bslabs : nullptr, M, L, taps, dilation, wg_rows);
   DRK_CHECK_LAUNCH();
+  const long n4 = (long)taps * WG_SLAB / 4;
+  hipLaunchKernelGGL(k_slab_reduce, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, ws, (int)chunks,
+                     (long)taps * WG_SLAB, dwt, n4);
+  DRK_CHECK_LAUNCH();
+  if (dbias) {
+    hipLaunchKernelGGL(k_slab_reduce, dim3(1), dim3(256), 0, stream, bslabs, (int)chunks, (long)DRK_C, dbias, (long)DRK_C / 4);
+    DRK_CHECK_LAUNCH();
+  }
   return DRK_OK;
+}
+
+extern "C" int drk_conv_wgrad_f32(const float* h, const float* dc, float* dwt, float* dbias, int B, int L, int taps,
+                                  int dilation, void* workspace, long workspace_bytes, void* stream) {
+  DRK_SHAPE_GUARD("drk_conv_wgrad_f32");
+  ARGCHECK(h && dc && dwt && taps >= 1 && taps <= WG_MAX_TAPS && (taps & 1) && dilation >= 0, "drk_conv_wgrad_f32");
+  ARGCHECK(workspace && ((uintptr_t)workspace & 15) == 0 && workspace_bytes >= drk_conv_wgrad_workspace_bytes(B, L, taps),
+           "drk_conv_wgrad_f32 (workspace: 16-byte aligned, drk_conv_wgrad_workspace_bytes(B, L, taps) bytes)");
+  return wgrad_launch(h, dc, dwt, dbias, (long)B * L, L, taps, dilation, (float*)workspace, (hipStream_t)stream);
 }
 
 extern "C" int drk_head_out_bwd(const float* dlogits, const float* y, const float* w, float* dy, float* dw, float* db,

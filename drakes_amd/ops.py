@@ -211,11 +211,31 @@ def ln_bwd(dh, feat, tbias_layer, tb_stride, gamma, mean, rstd, g_resid, dxin, d
               _f(dbeta, 'dbeta'), _f(dtb_shared, 'dtbias_shared'), B, L, _stream())
 
 
-def conv_wgrad_f32(h, dc, dwt, dilation, dbias=None):
-    """dwt [taps,128(ci),128(co)] += ...; dbias [128] += column sums of dc (optional)."""
+_WORKSPACE = {}
+
+
+def workspace(nbytes, device):
+    """A per-device scratch tensor of at least `nbytes` (split-K partial slabs).  Grown on demand, reused by every
+    call on that device: calls are ordered by the stream they share (torch's current stream); callers running several
+    streams pass their own workspace tensors instead."""
+    key = (device.type, device.index)
+    t = _WORKSPACE.get(key)
+    if t is None or t.numel() * 4 < nbytes:
+        t = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
+        _WORKSPACE[key] = t
+    return t
+
+
+def conv_wgrad_f32(h, dc, dwt, dilation, dbias=None, ws=None):
+    """dwt [taps,128(ci),128(co)] += ...; dbias [128] += column sums of dc (optional).  Deterministic: per-chunk partial
+    slabs in the workspace `ws`, summed in a fixed order."""
     B, L, _ = h.shape
-    _lib.call('drk_conv_wgrad_f32', _f(h, 'h'), _f(dc, 'dc'), _f(dwt, 'dwt'), _f(dbias, 'dbias'), B, L, dwt.shape[0], dilation,
-              _stream())
+    taps = dwt.shape[0]
+    need = _lib.load().drk_conv_wgrad_workspace_bytes(B, L, taps)
+    if ws is None:
+        ws = workspace(need, h.device)
+    _lib.call('drk_conv_wgrad_f32', _f(h, 'h'), _f(dc, 'dc'), _f(dwt, 'dwt'), _f(dbias, 'dbias'), B, L, taps, dilation,
+              _f(ws, 'workspace'), ws.numel() * 4, _stream())
 
 
 def head_out_bwd(dlogits, y, w, dy, dw, db):

@@ -143,7 +143,8 @@ int drk_head_out_fwd(const float* y, const float* w, const float* bias, float* l
 /* ---- backward ops (fp32) -----------------------------------------------------------------------
  * The reference gets these from torch autograd over CNNModel.forward (models/dnaconv.py:74-110),
  * _subs_parameterization (:243-253) and _ddpm_update_finetune_gradient (:552-586).  Parameter
- * gradients are ACCUMULATED (fp32 atomics) into buffers the caller zeroes. */
+ * gradients are ACCUMULATED into buffers the caller zeroes (the conv weight gradient by an ordered reduction,
+ * the small vectors by fp32 atomics). */
 /* out = g * mask (ReLU backward from the mask of drk_conv_fwd_f32); n % 4 == 0. */
 int drk_mask_mul(const float* g, const unsigned char* mask, float* out, long n, void* stream);
 /* out = g * (y > 0) (ReLU backward from a saved ReLU output); n % 4 == 0. */
@@ -157,9 +158,13 @@ int drk_ln_bwd(const float* dh, const float* feat, const float* tbias, long tbia
                const float* mean, const float* rstd, const float* g_resid, float* dxin, float* dfeat,
                float* dgamma, float* dbeta, float* dtbias_shared, int B, int L, void* stream);
 /* Conv1d weight gradient: dwt[t][ci][co] += sum_rows h[row + (t - taps/2)*dilation][ci] * dc[row][co].  dbias (optional, float32 [128], accumulated): column sums of dc,
- * the conv bias gradient, taken by the centre-tap workgroups on the way. */
+ * the conv bias gradient, taken by the centre-tap workgroups on the way.  Deterministic split-K: every (row chunk, tap)
+ * workgroup stores its 128x128 partial into `workspace` (device memory, 16-byte aligned, at least
+ * drk_conv_wgrad_workspace_bytes(B, L, taps) bytes, contents irrelevant before and after) and a second launch adds the
+ * partials in chunk order: the same bits on every run.  Calls sharing one workspace must be ordered (one stream). */
+long drk_conv_wgrad_workspace_bytes(int B, int L, int taps);   /* host-side size query; launches nothing */
 int drk_conv_wgrad_f32(const float* h, const float* dc, float* dwt, float* dbias, int B, int L, int taps, int dilation,
-                       void* stream);
+                       void* workspace, long workspace_bytes, void* stream);
 /* Backward of drk_head_out_fwd: dy [B][L][128]; dw [5][128], db [5] accumulated. */
 int drk_head_out_bwd(const float* dlogits, const float* y, const float* w, float* dy, float* dw, float* db,
                      int B, int L, void* stream);
