@@ -39,6 +39,7 @@ SIGNATURES = {
     'drk_colsum128': [_P, _P, c_long, c_long, _P],
     'drk_ln_bwd': [_P, _P, _P, c_long, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P],
     'drk_conv_wgrad_f32': [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, c_long, _P],
+    'drk_conv_wgrad_f32_static': [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P],
     'drk_head_out_bwd': [_P, _P, _P, _P, _P, _P, c_int, c_int, _P],
     'drk_stem_bwd': [_P, _P, _P, _P, _P, _P, c_int, c_int, _P],
     'drk_time_bwd': [_P, _P, c_int, _P, _P, _P, c_int, _P, _P, _P, _P, _P],

@@ -8,6 +8,8 @@
 #include "drk_common.h"
 #include "../../include/drakes_hip.h"
 
+#include <atomic>
+
 #define ARGCHECK(cond, name) \
   if (!(cond)) return drk_set_error_msg(DRK_EINVAL, name ": bad arguments")
 
@@ -801,6 +803,44 @@ extern "C" int drk_conv_wgrad_f32(const float* h, const float* dc, float* dwt, f
   ARGCHECK(workspace && ((uintptr_t)workspace & 15) == 0 && workspace_bytes >= drk_conv_wgrad_workspace_bytes(B, L, taps),
            "drk_conv_wgrad_f32 (workspace: 16-byte aligned, drk_conv_wgrad_workspace_bytes(B, L, taps) bytes)");
   return wgrad_launch(h, dc, dwt, dbias, (long)B * L, L, taps, dilation, (float*)workspace, (hipStream_t)stream);
+}
+
+// ---- the same, allocating nothing and taking no workspace -------------------------------------------------------
+// For callers that cannot call hipMalloc or carry a workspace (code under hipGraph capture, tight serving loops,
+// harnesses that forbid allocation).  The partial slabs live in a file-scope device array: WG_MAX_SLABS slabs of
+// 64 KB + their bias partials = 33.3 MB, held by every GPU the library runs on until the process ends.  In host code
+// the array's NAME is only a handle: its device address is taken once per device with hipGetSymbolAddress (each GPU
+// holds its own copy at its own address) and only that pointer is ever handed to a launch.
+#define WG_SCRATCH_FLOATS ((long)WG_MAX_SLABS * WG_SLAB + (long)WG_MAX_SLABS * DRK_C)
+#define WG_STATIC_MAX_ROWS (1L << 22)   // B * L accepted by the allocation-free form
+static __device__ __align__(256) float scratch[WG_SCRATCH_FLOATS];
+static std::atomic<float*> g_scratch_ptr[DRK_MAX_DEVICES];   // per device, set on the first call with that device current
+
+extern "C" int drk_conv_wgrad_f32_static(const float* h, const float* dc, float* dwt, float* dbias, int B, int L, int taps,
+                                         int dilation, void* stream) {
+  DRK_SHAPE_GUARD("drk_conv_wgrad_f32_static");
+  ARGCHECK(h && dc && dwt && taps >= 1 && (taps & 1) && dilation >= 0, "drk_conv_wgrad_f32_static");
+  const long M = (long)B * L;
+  if (taps > WG_MAX_TAPS || M > WG_STATIC_MAX_ROWS)
+    return drk_set_error_msg(DRK_EINVAL, "drk_conv_wgrad_f32_static: beyond the built-in scratch (taps <= 9, B*L <= 4194304 rows); "
+                                         "use drk_conv_wgrad_f32 with a workspace");
+  if (wgrad_ws_floats(M, taps) > WG_SCRATCH_FLOATS)
+    return drk_set_error_msg(DRK_EINVAL, "drk_conv_wgrad_f32_static: scratch too small for this shape");
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return drk_set_error(e, "drk_conv_wgrad_f32_static(hipGetDevice)");
+  if (dev < 0 || dev >= DRK_MAX_DEVICES) return drk_set_error_msg(DRK_EINVAL, "drk_conv_wgrad_f32_static: device index beyond DRK_MAX_DEVICES");
+  float* ws = g_scratch_ptr[dev].load(std::memory_order_acquire);
+  if (!ws) {   // first call on this device: resolve this device's copy of the array (not an allocation)
+    void* p = nullptr;
+    e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !p) return drk_set_error(e, "drk_conv_wgrad_f32_static(hipGetSymbolAddress)");
+    ws = (float*)p;
+    g_scratch_ptr[dev].store(ws, std::memory_order_release);
+  }
+  // every slab the reduction reads is fully written by this call's first launch, so the previous call's contents
+  // need no clearing; two calls overlapping on one GPU (different streams) would race on the array.
+  return wgrad_launch(h, dc, dwt, dbias, M, L, taps, dilation, ws, (hipStream_t)stream);
 }
 
 extern "C" int drk_head_out_bwd(const float* dlogits, const float* y, const float* w, float* dy, float* dw, float* db,

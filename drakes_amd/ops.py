@@ -184,6 +184,13 @@ def head_out_fwd(y, w, bias, out=None):
     return out
 
 
+def conv_wgrad_f32_static(h, dc, dwt, dilation, dbias=None):
+    """conv_wgrad_f32 through the allocation-free entry point (the partial slabs live inside the library)."""
+    B, L, _ = h.shape
+    _lib.call('drk_conv_wgrad_f32_static', _f(h, 'h'), _f(dc, 'dc'), _f(dwt, 'dwt'), _f(dbias, 'dbias'), B, L, dwt.shape[0],
+              dilation, _stream())
+
+
 # ---- backward ops ---------------------------------------------------------------------------------
 def mask_mul(g, mask, out=None):
     out = out if out is not None else torch.empty_like(g)

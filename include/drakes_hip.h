@@ -165,6 +165,14 @@ int drk_ln_bwd(const float* dh, const float* feat, const float* tbias, long tbia
 long drk_conv_wgrad_workspace_bytes(int B, int L, int taps);   /* host-side size query; launches nothing */
 int drk_conv_wgrad_f32(const float* h, const float* dc, float* dwt, float* dbias, int B, int L, int taps, int dilation,
                        void* workspace, long workspace_bytes, void* stream);
+/* drk_conv_wgrad_f32 without a workspace argument and without any allocation.  NO COUNTERPART IN THE REFERENCE: it
+ * exists for callers that cannot allocate or carry a workspace — code under hipGraph capture, tight serving loops,
+ * harnesses that forbid hipMalloc.  The partial slabs live in a 33.3 MB array inside the library's code object (one
+ * copy per GPU, held until the process ends).  Same arithmetic, same chunking, hence the same bits as
+ * drk_conv_wgrad_f32.  Limits: taps <= 9, B*L <= 4 194 304 rows (DRK_EINVAL beyond).  Every call on a GPU shares that
+ * GPU's array: calls that overlap on one GPU (different streams) race; calls ordered on one stream are safe. */
+int drk_conv_wgrad_f32_static(const float* h, const float* dc, float* dwt, float* dbias, int B, int L, int taps,
+                              int dilation, void* stream);
 /* Backward of drk_head_out_fwd: dy [B][L][128]; dw [5][128], db [5] accumulated. */
 int drk_head_out_bwd(const float* dlogits, const float* y, const float* w, float* dy, float* dw, float* db,
                      int B, int L, void* stream);
