@@ -37,12 +37,12 @@ SIGNATURES = {
     'drk_mask_mul': [_P, _P, _P, c_long, _P],
     'drk_relu_bwd': [_P, _P, _P, c_long, _P],
     'drk_colsum128': [_P, _P, c_long, c_long, _P],
-    'drk_ln_bwd': [_P, _P, _P, c_long, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P],
+    'drk_ln_bwd': [_P, _P, _P, c_long, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P],
     'drk_conv_wgrad_f32': [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, c_long, _P],
     'drk_conv_wgrad_f32_static': [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P],
     'drk_head_out_bwd': [_P, _P, _P, _P, _P, _P, c_int, c_int, _P],
     'drk_stem_bwd': [_P, _P, _P, _P, _P, _P, c_int, c_int, _P],
-    'drk_time_bwd': [_P, _P, c_int, _P, _P, _P, c_int, _P, _P, _P, _P, _P],
+    'drk_time_bwd': [_P, _P, c_int, _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P],
     'drk_subs_bwd': [_P, _P, _P, _P, _P, c_int, c_int, _P],
     'drk_reverse_step_soft_fwd': [_P, _P, _P, _P, _P, c_int, c_int, c_float, c_float, _P, c_float, c_float, c_uint64,
                                   c_uint32, c_uint64, _P],
@@ -51,14 +51,18 @@ SIGNATURES = {
     'drk_kl_step_fwd': [_P, _P, _P, _P, _P, c_float, _P, c_int, c_int, _P],
     'drk_kl_step_bwd': [_P, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P, c_int, c_int, _P],
     'drk_head_out_fwd': [_P, _P, _P, _P, c_int, c_int, _P],
-    'drk_layer_bf16': [_P, _P, _P, _P, _P, _P, _P, c_long, _P, _P, c_int, c_int, c_int, c_int, c_int, _P],
-    'drk_ln_fwd_bf16': [_P, _P, c_long, _P, _P, _P, c_int, c_int, _P],
+    'drk_layer_bf16': [_P, _P, _P, _P, _P, _P, _P, c_long, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P],
+    'drk_ln_fwd_bf16': [_P, _P, c_long, _P, _P, _P, _P, _P, c_int, c_int, _P],
+    'drk_gate_bf16': [_P, _P, _P, _P, _P, c_int, c_int, _P, c_long, _P],
+    'drk_conv_wgrad_bf16': [_P, _P, _P, c_int, c_int, c_int, c_int, _P, c_long, _P],
     'drk_sample_bf16': [_P, _P, _P, _P, _P, c_long, _P, _P, _P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, c_int,
                         c_uint64, c_uint64, c_int, _P],
 }
 
 HOST_QUERIES = {
     'drk_conv_wgrad_workspace_bytes': [c_int, c_int, c_int],
+    'drk_conv_wgrad_bf16_workspace_bytes': [c_int, c_int, c_int],
+    'drk_gate_bf16_workspace_bytes': [],
 }
 
 _lib = None

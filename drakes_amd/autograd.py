@@ -82,7 +82,7 @@ class _BackboneFn(torch.autograd.Function):
         dlogits = dlogits.contiguous()
         g = {}
         want_w = any(ctx.needs_input_grad[3:])     # a frozen model (the KL reference model) only passes the input gradient on
-        zeros = _ZeroPool((n * 9 * C * C if want_w else 0) + n * nb * C + (n + 2) * C * C + 16 * V * C + (6 * n + 16) * C, dlogits)
+        zeros = _ZeroPool((n * 9 * C * C if want_w else 0) + n * nb * C + (n + 2) * C * C + 16 * V * C + (6 * n + 16 + nb) * C, dlogits)
         # head
         dy = torch.empty_like(y)
         dw2, db2 = zeros(V, C), zeros(V)
@@ -134,7 +134,7 @@ class _BackboneFn(torch.autograd.Function):
         d_lin_w, d_lin_b = zeros(C, C), zeros(C)
         if want_w:
             ops.time_bwd(dtb.permute(1, 0, 2).contiguous(), ctx.sigma, pk['four_W'], ctx.temb, pk['dense_w'], d_dense_w,
-                         d_dense_b, d_lin_w, d_lin_b)
+                         d_dense_b, d_lin_w, d_lin_b, zeros(nb, C))
         g['time_embedder.1.weight'], g['time_embedder.1.bias'] = d_lin_w, d_lin_b
         for i in range(n):
             g[f'time_layers.{i}.dense.weight'], g[f'time_layers.{i}.dense.bias'] = d_dense_w[i], d_dense_b[i]
@@ -143,8 +143,133 @@ class _BackboneFn(torch.autograd.Function):
         return (None, dseq if ctx.needs_input_grad[1] else None, None, *grads)
 
 
-def backbone_with_grad(bb, seq, sigma):
-    return _BackboneFn.apply(bb, seq, sigma, *bb.parameters())
+class _BackboneBf16Fn(torch.autograd.Function):
+    """logits = CNNModel(seq, sigma) on the bf16-MFMA layer kernels, differentiable: bf16 LayerNorm outputs and conv
+    operands (forward, input gradient, weight gradient), fp32 accumulation, fp32 residual stream and residual-gradient
+    stream, fp32 LayerNorm statistics and backward, fp32 stem / 128->5 head / time path.  Saved per forward: the 21
+    residual snapshots (fp32), the 21 LayerNorm outputs (bf16: the weight gradient's operand), LayerNorm statistics and
+    uint8 ReLU masks."""
+
+    @staticmethod
+    def forward(ctx, bb, seq, sigma, *params):
+        from . import fastpath
+        pk, st = bb.packed(), fastpath._packed(bb)
+        vec, wstream = st['vecs'], st['wstream']
+        seq = seq.contiguous()
+        B, L = seq.shape[0], seq.shape[1]
+        n = bb.num_layers
+        dev = seq.device
+        sigma = sigma.to(torch.float32).contiguous()
+        nb = sigma.shape[0]
+        assert nb in (1, B), 'sigma: one value per row or one shared value'
+        temb = ops.time_embed_fwd(sigma, pk['four_W'], pk['temb_w'], pk['temb_b'])
+        tbias = ops.time_bias_fwd(temb, pk['dense_w'], pk['dense_b'])
+        tb_stride = tbias.stride(0) if nb == B and B > 1 else 0
+        f32 = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
+        b16 = lambda: torch.empty(B, L, C, dtype=torch.bfloat16, device=dev)
+        feats = [ops.stem_fwd(seq, pk['stem_w'], pk['stem_b'])]
+        means, rstds, masks = [f32(B * L)], [f32(B * L)], []
+        hs = [ops.ln_fwd_bf16(feats[0], tbias[0, 0], tb_stride, vec[1], vec[2], mean=means[0], rstd=rstds[0])]
+        for i in range(n):
+            last = i + 1 == n
+            mask = torch.empty(B, L, C, dtype=torch.uint8, device=dev)
+            if not last:
+                means.append(f32(B * L)), rstds.append(f32(B * L))
+            hs.append(b16())
+            feats.append(ops.layer_bf16(
+                hs[i], wstream[9 * i:], f32(B, L, C), feat=feats[i], h_out=hs[i + 1], bias=vec[3 * (i + 1)],
+                tbias=None if last else tbias[0, i + 1], tb_stride=tb_stride, gamma=None if last else vec[3 * (i + 1) + 1],
+                beta=None if last else vec[3 * (i + 1) + 2], taps=9, dilation=bb.dilation(i), relu=True, relu_mask=mask,
+                mean=None if last else means[i + 1], rstd=None if last else rstds[i + 1]))
+            masks.append(mask)
+        # hs[n] = bf16(feat_n): final_conv.0 (1x1) + ReLU on the same kernel, then the exact-fp32 128 -> 5 conv
+        y = ops.layer_bf16(hs[n], wstream[9 * n:], f32(B, L, C), bias=vec[3 * n + 1], taps=1, dilation=0, relu=True)
+        logits = ops.head_out_fwd(y, pk['head2_w'], pk['head2_b'])
+        ctx.bb, ctx.pk, ctx.seq, ctx.sigma, ctx.temb, ctx.tbias, ctx.tb_stride = bb, pk, seq, sigma, temb, tbias, tb_stride
+        ctx.feats, ctx.hs, ctx.means, ctx.rstds, ctx.masks, ctx.y = feats, hs, means, rstds, masks, y
+        ctx.names = [k for k, _ in bb.named_parameters()]
+        if _BackboneBf16Fn.gate_log is not None:   # tests: the ReLU gates this forward took (see oracle/bf16_emulation.py)
+            _BackboneBf16Fn.gate_log.append((masks, y, feats[0]))
+        return logits
+
+    gate_log = None          # tests set this to a list; every bf16 forward under autograd then appends (masks, y, feats[0])
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        from . import fastpath
+        bb, pk, seq = ctx.bb, ctx.pk, ctx.seq
+        feats, hs, means, rstds, masks, y = ctx.feats, ctx.hs, ctx.means, ctx.rstds, ctx.masks, ctx.y
+        B, L = seq.shape[0], seq.shape[1]
+        M, n = B * L, bb.num_layers
+        nb = ctx.sigma.shape[0]
+        dlogits = dlogits.contiguous()
+        g = {}
+        want_w = any(ctx.needs_input_grad[3:])
+        wT = fastpath._packed_T(bb)
+        zeros = _ZeroPool((n * 9 * C * C if want_w else 0) + n * nb * C + (n + 2) * C * C + 16 * V * C + (6 * n + 16 + nb) * C, dlogits)
+        # head: exact-fp32 128 -> 5 backward, then final_conv.0 on the bf16 kernels
+        dy = torch.empty_like(y)
+        dw2, db2 = zeros(V, C), zeros(V)
+        ops.head_out_bwd(dlogits, y, pk['head2_w'], dy, dw2, db2)
+        dw0, db0 = zeros(1, C, C), zeros(C)
+        dc = ops.gate_bf16(dy, y=y, colsum=db0 if want_w else None)
+        if want_w:
+            ops.conv_wgrad_bf16(hs[n], dc, dw0, 0)
+        gr = ops.layer_bf16(dc, wT[9 * n:], dy, taps=1, dilation=0, relu=False)       # dy's storage becomes dL/dfeat_n
+        g['final_conv.2.weight'], g['final_conv.2.bias'] = dw2.unsqueeze(-1), db2
+        g['final_conv.0.weight'], g['final_conv.0.bias'] = dw0.permute(2, 1, 0), db0
+        dtb = zeros(n, nb, C)
+        dh = torch.empty_like(y)
+        dxin = torch.empty_like(y) if (want_w and ctx.tb_stride) else None      # only the per-row time-bias gradient reads it
+        dbias = zeros(C)
+        ops.gate_bf16(gr, relu_mask=masks[n - 1], colsum=dbias if want_w else None, out=dc)
+        dc_next = torch.empty_like(dc)
+        for i in reversed(range(n)):
+            d = bb.dilation(i)
+            if want_w:
+                dwt = zeros(9, C, C)
+                ops.conv_wgrad_bf16(hs[i], dc, dwt, d)
+                g[f'convs.{i}.weight'], g[f'convs.{i}.bias'] = dwt.permute(2, 1, 0), dbias
+            ops.layer_bf16(dc, wT[9 * i:], dh, taps=9, dilation=d, relu=False)
+            dgam, dbet = zeros(C), zeros(C)
+            gnew = torch.empty_like(y)
+            shared_tb = want_w and not ctx.tb_stride
+            dbias = zeros(C)                                        # of layer i - 1, filled by the fused hand-over
+            ops.ln_bwd(dh, feats[i], ctx.tbias[0, i], ctx.tb_stride, pk['ln_g'][i], means[i], rstds[i], gr, dxin, gnew,
+                       dgam, dbet, dtb[i, 0] if shared_tb else None, next_mask=masks[i - 1] if i else None,
+                       dc_next=dc_next if i else None, dbias_next=dbias if (i and want_w) else None)
+            g[f'norms.{i}.weight'], g[f'norms.{i}.bias'] = dgam, dbet
+            if want_w and ctx.tb_stride:
+                ops.colsum128(dxin, B, L, dtb[i])
+            gr = gnew
+            dc, dc_next = dc_next, dc
+        # stem and time path: the fp32 kernels
+        dpre = ops.relu_bwd(gr, feats[0], out=gr)
+        if want_w:
+            g['linear.bias'] = ops.colsum128(dpre, 1, M, zeros(1, C))[0]
+        dw_t = zeros(9, V, C)
+        dseq = None
+        if seq.dtype != torch.int64:
+            dseq = torch.empty_like(seq)
+        ops.stem_bwd(dpre, seq, pk['stem_w'], dw_t, dseq)
+        g['linear.weight'] = dw_t.permute(2, 1, 0)
+        d_dense_w, d_dense_b = zeros(n, C, C), zeros(n, C)
+        d_lin_w, d_lin_b = zeros(C, C), zeros(C)
+        if want_w:
+            ops.time_bwd(dtb.permute(1, 0, 2).contiguous(), ctx.sigma, pk['four_W'], ctx.temb, pk['dense_w'], d_dense_w,
+                         d_dense_b, d_lin_w, d_lin_b, zeros(nb, C))
+        g['time_embedder.1.weight'], g['time_embedder.1.bias'] = d_lin_w, d_lin_b
+        for i in range(n):
+            g[f'time_layers.{i}.dense.weight'], g[f'time_layers.{i}.dense.bias'] = d_dense_w[i], d_dense_b[i]
+        grads = [g.get(k) if ctx.needs_input_grad[3 + j] else None for j, k in enumerate(ctx.names)]
+        ctx.feats = ctx.hs = ctx.masks = ctx.means = ctx.rstds = ctx.y = None
+        return (None, dseq if ctx.needs_input_grad[1] else None, None, *grads)
+
+
+def backbone_with_grad(bb, seq, sigma, bf16=False):
+    """bf16: the bf16-MFMA layer kernels (gradients within the bf16 bar); default: the exact-fp32 kernels."""
+    fn = _BackboneBf16Fn if bf16 else _BackboneFn
+    return fn.apply(bb, seq, sigma, *bb.parameters())
 
 
 class _SubsFn(torch.autograd.Function):

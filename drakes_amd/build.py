@@ -22,6 +22,7 @@ SOURCES = {
     'drk_sample_bf16.hip': ['-ffp-contract=off'],
     'drk_train_f32.hip': ['-ffp-contract=off'],
     'drk_layer_bf16.hip': ['-ffp-contract=off'],
+    'drk_train_bf16.hip': ['-ffp-contract=off'],
 }
 COMMON = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function']
 

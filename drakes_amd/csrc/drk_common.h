@@ -102,5 +102,10 @@ __device__ __forceinline__ int drk_gumbel_argmax(const float q[DRK_V], const flo
   if (B < 0 || L <= 0) return drk_set_error_msg(DRK_EINVAL, name ": bad shape");     \
   if (B == 0) return DRK_OK
 
+// out[i] += slabs[0][i] + slabs[1][i] + ... + slabs[n_slabs-1][i] in that order, i < n (n % 4 == 0, every pointer
+// 16-byte aligned); slab s starts at slabs + s * stride.  The ordered second pass of every split-K reduction here
+// (defined in drk_train_f32.hip).
+int drk_slab_reduce_launch(const float* slabs, int n_slabs, long stride, float* out, long n, hipStream_t stream);
+
 int drk_set_error(hipError_t e, const char* where);
 int drk_set_error_msg(int code, const char* msg);

@@ -38,7 +38,11 @@ struct LayerArgs {
   float* feat_out;          // fp32 [M][128]
   char* h_out;              // bf16 [M][128] (NULL: not needed)
   const char* wfrag;        // this layer's taps in fragment order
-  const float* bias;        // [128]
+  const float* bias;        // [128] (NULL: none — the input-gradient use)
+  unsigned char* mask_out;  // optional uint8 [M][128]: (pre-activation > 0), kept for the backward pass
+  float* mean_out;          // optional [M]: statistics of the NEXT LayerNorm (ln = 1), kept for the backward pass
+  float* rstd_out;
+  int relu;                 // 0: feat_out = conv(h) (+ bias) (+ feat), no ReLU (the convolution's input gradient)
   const float* tbias;       // next LayerNorm's time bias [128] per batch row (stride tb_stride) or shared; NULL with ln = 0
   long tb_stride;
   const float* gamma;       // next LayerNorm's affine [128] (ln = 1)
@@ -218,7 +222,8 @@ __global__ void __launch_bounds__(256, WGS) k_layer_bf16(const LayerArgs a) {
   // ---- epilogue ---------------------------------------------------------------------------------------------------
   {
 #pragma clang fp contract(fast)
-  const f32x4 cb0 = *(const f32x4*)(a.bias + ch0), cb1 = *(const f32x4*)(a.bias + ch0 + 16);
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  const f32x4 cb0 = a.bias ? *(const f32x4*)(a.bias + ch0) : zero4, cb1 = a.bias ? *(const f32x4*)(a.bias + ch0 + 16) : zero4;
   f32x4 x[LT_NT][2];
 #pragma unroll
   for (int t = 0; t < LT_NT; ++t) {
@@ -227,9 +232,16 @@ __global__ void __launch_bounds__(256, WGS) k_layer_bf16(const LayerArgs a) {
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const f32x4 cb = s ? cb1 : cb0;
-      f32x4 r;
+      f32x4 r = acc[t][s] + cb;
+      if (a.relu) {
+        if (a.mask_out && ok) {   // this lane's 4 channels of one row: 4 bytes; the 4 lane groups of a row make 16 contiguous bytes
+          const unsigned m = (r[0] > 0.f ? 1u : 0u) | (r[1] > 0.f ? 0x100u : 0u) | (r[2] > 0.f ? 0x10000u : 0u) |
+                             (r[3] > 0.f ? 0x1000000u : 0u);
+          *(unsigned*)(a.mask_out + row * DRK_C + ch0 + 16 * s) = m;
+        }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) r[i] = fmaxf(acc[t][s][i] + cb[i], 0.f);
+        for (int i = 0; i < 4; ++i) r[i] = fmaxf(r[i], 0.f);
+      }
       if constexpr (PRE) {
         r += res[t][s];
       } else {
@@ -282,6 +294,10 @@ __global__ void __launch_bounds__(256, WGS) k_layer_bf16(const LayerArgs a) {
       const float var = fmaxf(s2 * (1.0f / 128.0f) - mean * mean, 0.0f);
       const float rstd = __builtin_amdgcn_rsqf(var + 1e-5f);
       const float c = -mean * rstd;
+      if (a.mean_out && ct == 0 && g == 0 && r0 + 16 * t + pn < a.M) {
+        a.mean_out[r0 + 16 * t + pn] = mean;
+        a.rstd_out[r0 + 16 * t + pn] = rstd;
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         x[t][0][i] = (x[t][0][i] * rstd + c) * g0[i] + b0[i];
@@ -312,7 +328,8 @@ __global__ void __launch_bounds__(256, WGS) k_layer_bf16(const LayerArgs a) {
 // LayerNorm(feat + tbias) * gamma + beta -> bf16 rows: the first layer's input (after the stem).  32 lanes per row.
 __global__ void __launch_bounds__(256) k_ln_bf16(const float* __restrict__ feat, const float* __restrict__ tbias, long tb_stride,
                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                 char* __restrict__ h, long M, int L) {
+                                                 char* __restrict__ h, float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                 long M, int L) {
   const int lr = threadIdx.x & 31;
   const long row = (long)blockIdx.x * 8 + (threadIdx.x >> 5);
   if (row >= M) return;
@@ -328,6 +345,10 @@ __global__ void __launch_bounds__(256) k_ln_bf16(const float* __restrict__ feat,
   const float mean = s1 * (1.0f / 128.0f);
   const float var = fmaxf(s2 * (1.0f / 128.0f) - mean * mean, 0.0f);
   const float rstd = __builtin_amdgcn_rsqf(var + 1e-5f);
+  if (mean_out && lr == 0) {
+    mean_out[row] = mean;
+    rstd_out[row] = rstd;
+  }
   const f32x4 gm = *(const f32x4*)(gamma + 4 * lr), be = *(const f32x4*)(beta + 4 * lr);
   bf16v4 pk;
 #pragma unroll
@@ -340,11 +361,16 @@ __global__ void __launch_bounds__(256) k_ln_bf16(const float* __restrict__ feat,
 
 extern "C" int drk_layer_bf16(const void* h, const float* feat, float* feat_out, void* h_out, const void* wfrag,
                               const float* bias, const float* tbias, long tb_stride, const float* gamma,
-                              const float* beta, int B, int L, int taps, int dilation, int ln, void* stream) {
+                              const float* beta, int B, int L, int taps, int dilation, int ln, int relu,
+                              unsigned char* relu_mask, float* mean, float* rstd, void* stream) {
   DRK_SHAPE_GUARD("drk_layer_bf16");
-  LARGCHECK(h && feat_out && wfrag && bias && taps >= 1 && (taps & 1) && dilation >= 0, "drk_layer_bf16");
+  LARGCHECK(h && feat_out && wfrag && taps >= 1 && (taps & 1) && dilation >= 0, "drk_layer_bf16");
   LARGCHECK(!ln || (h_out && tbias && gamma && beta), "drk_layer_bf16 (LayerNorm parameters)");
+  LARGCHECK((!mean && !rstd) || (mean && rstd && ln), "drk_layer_bf16 (mean / rstd come with ln = 1, both or neither)");
+  LARGCHECK(!relu_mask || relu, "drk_layer_bf16 (a ReLU mask needs relu = 1)");
+  LARGCHECK((const void*)h != (const void*)h_out, "drk_layer_bf16 (h and h_out must be distinct buffers)");
   LayerArgs a;
+  a.mask_out = relu_mask; a.mean_out = mean; a.rstd_out = rstd; a.relu = relu ? 1 : 0;
   a.h = (const char*)h; a.feat = feat; a.feat_out = feat_out; a.h_out = (char*)h_out; a.wfrag = (const char*)wfrag;
   a.bias = bias; a.tbias = tbias; a.tb_stride = tb_stride; a.gamma = gamma; a.beta = beta;
   a.M = (long)B * L; a.L = L; a.taps = taps; a.dil = dilation; a.ln = ln ? 1 : 0;
@@ -365,12 +391,12 @@ extern "C" int drk_layer_bf16(const void* h, const float* feat, float* feat_out,
 }
 
 extern "C" int drk_ln_fwd_bf16(const float* feat, const float* tbias, long tb_stride, const float* gamma, const float* beta,
-                               void* h, int B, int L, void* stream) {
+                               void* h, float* mean, float* rstd, int B, int L, void* stream) {
   DRK_SHAPE_GUARD("drk_ln_fwd_bf16");
-  LARGCHECK(feat && gamma && beta && h, "drk_ln_fwd_bf16");
+  LARGCHECK(feat && gamma && beta && h && (!mean == !rstd), "drk_ln_fwd_bf16");
   const long M = (long)B * L;
   hipLaunchKernelGGL(k_ln_bf16, dim3((unsigned)((M + 7) / 8)), dim3(256), 0, (hipStream_t)stream, feat, tbias, tb_stride, gamma,
-                     beta, (char*)h, M, L);
+                     beta, (char*)h, mean, rstd, M, L);
   DRK_CHECK_LAUNCH();
   return DRK_OK;
 }

@@ -68,11 +68,12 @@ __global__ void __launch_bounds__(256) k_ln_bwd(const float* __restrict__ dh, co
                                                 const float* __restrict__ rstd, const float* __restrict__ g_resid,
                                                 float* __restrict__ dxin, float* __restrict__ dfeat,
                                                 float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                float* __restrict__ dtb, long M, int L) {
-  __shared__ float pg[8][128], pb[8][128], px[8][128];
+                                                float* __restrict__ dtb, const unsigned char* __restrict__ next_mask,
+                                                char* __restrict__ dc_next, float* __restrict__ dbias_next, long M, int L) {
+  __shared__ float pg[8][128], pb[8][128], px[8][128], pc[8][128];
   const int lr = threadIdx.x & 31, sub = threadIdx.x >> 5;
   const f32x4 gm = *(const f32x4*)(gamma + 4 * lr);
-  f32x4 ag = {0.f, 0.f, 0.f, 0.f}, ab = {0.f, 0.f, 0.f, 0.f}, ax = {0.f, 0.f, 0.f, 0.f};
+  f32x4 ag = {0.f, 0.f, 0.f, 0.f}, ab = {0.f, 0.f, 0.f, 0.f}, ax = {0.f, 0.f, 0.f, 0.f}, ac = {0.f, 0.f, 0.f, 0.f};
   for (long row = (long)blockIdx.x * 64 + sub; row < (long)blockIdx.x * 64 + 64 && row < M; row += 8) {
     const long b = row / L;
     f32x4 x = *(const f32x4*)(feat + row * DRK_C + 4 * lr);
@@ -90,10 +91,19 @@ __global__ void __launch_bounds__(256) k_ln_bwd(const float* __restrict__ dh, co
     }
     const float m1 = s1 * (1.0f / DRK_C), m2 = s2 * (1.0f / DRK_C);
     const f32x4 dx = (dyg - m1 - xh * m2) * rs;
-    *(f32x4*)(dxin + row * DRK_C + 4 * lr) = dx;
+    if (dxin) *(f32x4*)(dxin + row * DRK_C + 4 * lr) = dx;
     f32x4 o = dx;
     if (g_resid) o += *(const f32x4*)(g_resid + row * DRK_C + 4 * lr);
     *(f32x4*)(dfeat + row * DRK_C + 4 * lr) = o;
+    if (next_mask) {   // the layer below: dc = bf16(dfeat * its ReLU mask), and the column sums = its conv bias gradient
+      const unsigned m = *(const unsigned*)(next_mask + row * DRK_C + 4 * lr);
+      const f32x4 v = {(m & 0xffu) ? o[0] : 0.f, (m & 0xff00u) ? o[1] : 0.f, (m & 0xff0000u) ? o[2] : 0.f, (m & 0xff000000u) ? o[3] : 0.f};
+      typedef __bf16 bf16v4_t __attribute__((ext_vector_type(4)));
+      bf16v4_t pk;
+      pk[0] = (__bf16)v[0]; pk[1] = (__bf16)v[1]; pk[2] = (__bf16)v[2]; pk[3] = (__bf16)v[3];
+      *(bf16v4_t*)(dc_next + row * 256 + 8 * lr) = pk;
+      ac += v;
+    }
     ag += d * xh;
     ab += d;
     ax += dx;
@@ -101,6 +111,7 @@ __global__ void __launch_bounds__(256) k_ln_bwd(const float* __restrict__ dh, co
   *(f32x4*)(&pg[sub][4 * lr]) = ag;
   *(f32x4*)(&pb[sub][4 * lr]) = ab;
   *(f32x4*)(&px[sub][4 * lr]) = ax;
+  *(f32x4*)(&pc[sub][4 * lr]) = ac;
   __syncthreads();
   if (threadIdx.x < 128) {
     float sg = 0.f, sb = 0.f;
@@ -116,6 +127,12 @@ __global__ void __launch_bounds__(256) k_ln_bwd(const float* __restrict__ dh, co
 #pragma unroll
       for (int k = 0; k < 8; ++k) sx += px[k][threadIdx.x];
       atomicAdd(dtb + threadIdx.x, sx);
+    }
+    if (dbias_next) {
+      float sc = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) sc += pc[k][threadIdx.x];
+      atomicAdd(dbias_next + threadIdx.x, sc);
     }
   }
 }
@@ -209,8 +226,17 @@ __global__ void __launch_bounds__(256) k_conv_wgrad(const float* __restrict__ h,
 __global__ void __launch_bounds__(256) k_slab_reduce(const float* __restrict__ slabs, int n_slabs, long stride,
                                                      float* __restrict__ out, long n4) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
-    f32x4 s = ((const f32x4*)slabs)[i];
-    for (int k = 1; k < n_slabs; ++k) s += ((const f32x4*)(slabs + k * stride))[i];
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < n_slabs; k0 += 8) {   // 8 independent loads in flight, then added in slab order
+      f32x4 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (k0 + j < n_slabs) v[j] = ((const f32x4*)(slabs + (long)(k0 + j) * stride))[i];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += v[j];
+    }
     ((f32x4*)out)[i] += s;
   }
 }
@@ -332,36 +358,40 @@ __global__ void __launch_bounds__(256) k_stem_dgrad(const float* __restrict__ dp
 
 // ------------------------------------------------------------------------------------ time path backward
 // tbias[b][l][c] = dense_w[l][c][:] . temb[b][:] + dense_b[l][c];  temb = relu(lin_w . four + lin_b); four = sin/cos(sigma*W*2pi)
-// One workgroup (128 threads) per batch row; W (the Fourier frequencies) is not trained (dnaconv.py:17).
-__global__ void __launch_bounds__(128) k_time_bwd(const float* __restrict__ dtbias, const float* __restrict__ sigma,
-                                                  const float* __restrict__ W, const float* __restrict__ temb,
-                                                  const float* __restrict__ dense_w, float* __restrict__ d_dense_w,
-                                                  float* __restrict__ d_dense_b, float* __restrict__ d_lin_w,
-                                                  float* __restrict__ d_lin_b, int n_layers) {
-  __shared__ float te[DRK_C], dt[DRK_C], dpre[DRK_C], four[DRK_C];
-  const int b = blockIdx.x, c = threadIdx.x;
-  te[c] = temb[(long)b * DRK_C + c];
-  const float proj = ((sigma[b] * W[c & 63]) * 2.0f) * 3.14159274101257324f;
-  four[c] = (c < 64) ? sinf(proj) : cosf(proj);
-  float dtemb = 0.f;
-  for (int l = 0; l < n_layers; ++l) {
-    __syncthreads();
-    dt[c] = dtbias[((long)b * n_layers + l) * DRK_C + c];
-    __syncthreads();
-    atomicAdd(d_dense_b + l * DRK_C + c, dt[c]);
-    const float* wl = dense_w + (long)l * DRK_C * DRK_C;
-    float* dwl = d_dense_w + (long)l * DRK_C * DRK_C;
-    // thread c = INPUT index j here: dtemb[j] += sum_o dt[o] * w[o][j];  d_w[o][j] += dt[o] * te[j]
-    for (int o = 0; o < DRK_C; ++o) {
-      dtemb += dt[o] * wl[o * DRK_C + c];
-      atomicAdd(dwl + o * DRK_C + c, dt[o] * te[c]);
-    }
-  }
+// W (the Fourier frequencies) is not trained (dnaconv.py:17).  Two launches: one workgroup per (batch row, layer) for
+// the Dense layers (their contributions to dtemb meet in `dtemb`, float32 [nb][128], zeroed by the caller), then one
+// workgroup per batch row for the embedding's Linear.
+__global__ void __launch_bounds__(128) k_time_bwd_dense(const float* __restrict__ dtbias, const float* __restrict__ temb,
+                                                        const float* __restrict__ dense_w, float* __restrict__ d_dense_w,
+                                                        float* __restrict__ d_dense_b, float* __restrict__ dtemb, int n_layers) {
+  __shared__ float dt[DRK_C];
+  const int b = blockIdx.x, l = blockIdx.y, c = threadIdx.x;
+  const float te = temb[(long)b * DRK_C + c];
+  dt[c] = dtbias[((long)b * n_layers + l) * DRK_C + c];
   __syncthreads();
-  dpre[c] = te[c] > 0.f ? dtemb : 0.f;
+  atomicAdd(d_dense_b + l * DRK_C + c, dt[c]);
+  const float* wl = dense_w + (long)l * DRK_C * DRK_C;
+  float* dwl = d_dense_w + (long)l * DRK_C * DRK_C;
+  // thread c = INPUT index j here: dtemb[j] += sum_o dt[o] * w[o][j];  d_w[o][j] += dt[o] * te[j]
+  float acc = 0.f;
+  for (int o = 0; o < DRK_C; ++o) {
+    acc += dt[o] * wl[o * DRK_C + c];
+    atomicAdd(dwl + o * DRK_C + c, dt[o] * te);
+  }
+  atomicAdd(dtemb + (long)b * DRK_C + c, acc);
+}
+
+__global__ void __launch_bounds__(128) k_time_bwd_embed(const float* __restrict__ dtemb, const float* __restrict__ sigma,
+                                                        const float* __restrict__ W, const float* __restrict__ temb,
+                                                        float* __restrict__ d_lin_w, float* __restrict__ d_lin_b) {
+  __shared__ float dpre[DRK_C];
+  const int b = blockIdx.x, c = threadIdx.x;
+  const float proj = ((sigma[b] * W[c & 63]) * 2.0f) * 3.14159274101257324f;
+  const float four = (c < 64) ? sinf(proj) : cosf(proj);
+  dpre[c] = temb[(long)b * DRK_C + c] > 0.f ? dtemb[(long)b * DRK_C + c] : 0.f;
   __syncthreads();
   atomicAdd(d_lin_b + c, dpre[c]);
-  for (int o = 0; o < DRK_C; ++o) atomicAdd(d_lin_w + o * DRK_C + c, dpre[o] * four[c]);
+  for (int o = 0; o < DRK_C; ++o) atomicAdd(d_lin_w + o * DRK_C + c, dpre[o] * four);
 }
 
 // ------------------------------------------------------------------------------------ SUBS backward
@@ -745,12 +775,23 @@ extern "C" int drk_colsum128(const float* x, float* out, long n_seg, long seg_ro
 
 extern "C" int drk_ln_bwd(const float* dh, const float* feat, const float* tbias, long tbias_bstride, const float* gamma,
                           const float* mean, const float* rstd, const float* g_resid, float* dxin, float* dfeat,
-                          float* dgamma, float* dbeta, float* dtbias_shared, int B, int L, void* stream) {
+                          float* dgamma, float* dbeta, float* dtbias_shared, const unsigned char* next_mask, void* dc_next,
+                          float* dbias_next, int B, int L, void* stream) {
   DRK_SHAPE_GUARD("drk_ln_bwd");
-  ARGCHECK(dh && feat && gamma && mean && rstd && dxin && dfeat && dgamma && dbeta, "drk_ln_bwd");
+  ARGCHECK(dh && feat && gamma && mean && rstd && dfeat && dgamma && dbeta, "drk_ln_bwd");
+  ARGCHECK((!next_mask && !dc_next && !dbias_next) || (next_mask && dc_next), "drk_ln_bwd (next_mask and dc_next come together)");
   const long M = (long)B * L;
   hipLaunchKernelGGL(k_ln_bwd, dim3((unsigned)((M + 63) / 64)), dim3(256), 0, (hipStream_t)stream, dh, feat, tbias,
-                     tbias_bstride, gamma, mean, rstd, g_resid, dxin, dfeat, dgamma, dbeta, dtbias_shared, M, L);
+                     tbias_bstride, gamma, mean, rstd, g_resid, dxin, dfeat, dgamma, dbeta, dtbias_shared, next_mask, (char*)dc_next, dbias_next, M, L);
+  DRK_CHECK_LAUNCH();
+  return DRK_OK;
+}
+
+int drk_slab_reduce_launch(const float* slabs, int n_slabs, long stride, float* out, long n, hipStream_t stream) {
+  const long n4 = n / 4;
+  long grid = (n4 + 255) / 256;
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(k_slab_reduce, dim3((unsigned)grid), dim3(256), 0, stream, slabs, n_slabs, stride, out, n4);
   DRK_CHECK_LAUNCH();
   return DRK_OK;
 }
@@ -785,15 +826,9 @@ static int wgrad_launch(const float* h, const float* dc, float* dwt, float* dbia
   hipLaunchKernelGGL(k_conv_wgrad, dim3((unsigned)chunks, (unsigned)taps), dim3(256), 0, stream, h, dc, ws,
                      dbias ? bslabs : nullptr, M, L, taps, dilation, wg_rows);
   DRK_CHECK_LAUNCH();
-  const long n4 = (long)taps * WG_SLAB / 4;
-  hipLaunchKernelGGL(k_slab_reduce, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, ws, (int)chunks,
-                     (long)taps * WG_SLAB, dwt, n4);
-  DRK_CHECK_LAUNCH();
-  if (dbias) {
-    hipLaunchKernelGGL(k_slab_reduce, dim3(1), dim3(256), 0, stream, bslabs, (int)chunks, (long)DRK_C, dbias, (long)DRK_C / 4);
-    DRK_CHECK_LAUNCH();
-  }
-  return DRK_OK;
+  int rc = drk_slab_reduce_launch(ws, (int)chunks, (long)taps * WG_SLAB, dwt, (long)taps * WG_SLAB, stream);
+  if (rc == DRK_OK && dbias) rc = drk_slab_reduce_launch(bslabs, (int)chunks, (long)DRK_C, dbias, (long)DRK_C, stream);
+  return rc;
 }
 
 extern "C" int drk_conv_wgrad_f32(const float* h, const float* dc, float* dwt, float* dbias, int B, int L, int taps,
@@ -871,12 +906,14 @@ extern "C" int drk_stem_bwd(const float* dpre, const int64_t* x, const float* x_
 
 extern "C" int drk_time_bwd(const float* dtbias, const float* sigma, int nb, const float* W, const float* temb,
                             const float* dense_w, int n_layers, float* d_dense_w, float* d_dense_b, float* d_lin_w,
-                            float* d_lin_b, void* stream) {
-  ARGCHECK(nb >= 0 && n_layers > 0, "drk_time_bwd");
+                            float* d_lin_b, float* dtemb, void* stream) {
+  ARGCHECK(nb >= 0 && n_layers > 0 && n_layers < 65536, "drk_time_bwd");
   if (nb == 0) return DRK_OK;
-  ARGCHECK(dtbias && sigma && W && temb && dense_w && d_dense_w && d_dense_b && d_lin_w && d_lin_b, "drk_time_bwd");
-  hipLaunchKernelGGL(k_time_bwd, dim3(nb), dim3(128), 0, (hipStream_t)stream, dtbias, sigma, W, temb, dense_w, d_dense_w,
-                     d_dense_b, d_lin_w, d_lin_b, n_layers);
+  ARGCHECK(dtbias && sigma && W && temb && dense_w && d_dense_w && d_dense_b && d_lin_w && d_lin_b && dtemb, "drk_time_bwd");
+  hipLaunchKernelGGL(k_time_bwd_dense, dim3(nb, n_layers), dim3(128), 0, (hipStream_t)stream, dtbias, temb, dense_w,
+                     d_dense_w, d_dense_b, dtemb, n_layers);
+  DRK_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_time_bwd_embed, dim3(nb), dim3(128), 0, (hipStream_t)stream, dtemb, sigma, W, temb, d_lin_w, d_lin_b);
   DRK_CHECK_LAUNCH();
   return DRK_OK;
 }

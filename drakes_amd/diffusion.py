@@ -45,6 +45,7 @@ class Diffusion(nn.Module):
         self.time_conditioning = self.config.time_conditioning
         self.neg_infinity = -1000000.0
         self.hip_dtype = 'fp32'
+        self.hip_soft_dtype = None      # differentiable (Gumbel-softmax) steps: None = follow hip_dtype; 'fp32' | 'bf16'
         self.hip_graph = False          # fp32 path: replay the step loop from a captured hipGraph (see _sample_graph)
         self._graph = None
         self._validate_configuration()
@@ -60,6 +61,10 @@ class Diffusion(nn.Module):
     @property
     def dtype(self):
         return torch.float32
+
+    def _soft_dtype(self):
+        """Arithmetic of the differentiable denoiser forwards / backwards (soft steps, forward() under grad)."""
+        return self.hip_soft_dtype or self.hip_dtype
 
     def refresh_weights(self):
         """Call after writing parameters in a way torch's version counter does not see (`p.data.copy_(...)`,
@@ -91,6 +96,7 @@ class Diffusion(nn.Module):
     def forward(self, x, sigma):
         """Returns log score — reference :266-275."""
         sigma = self._process_sigma(sigma)
+        self.backbone.train_dtype = self._soft_dtype()
         logits = self.backbone(x, sigma)
         return self._subs_parameterization(logits=logits, xt=x)
 

@@ -69,6 +69,28 @@ def pack_stream(bb):
         }
 
 
+def pack_stream_T(bb):
+    """The fragment stream of the convolutions' INPUT gradients: per layer the 9 taps of weight.transpose(0,1).flip(2)
+    (dh[r][ci] = sum_t sum_co dc[r + (t-4)d][co] * w[co][ci][8-t]), then final_conv.0 transposed."""
+    n = bb.num_layers
+    with torch.no_grad():
+        stages = []
+        for i in range(n):
+            wt = bb.convs[i].weight.transpose(0, 1).flip(2)          # [ci][co][tap]
+            for t in range(9):
+                stages.append(_frag_tap(wt[:, :, t]))
+        stages.append(_frag_tap(bb.final_conv[0].weight[:, :, 0].t()))
+        return torch.stack(stages).contiguous()
+
+
+def _packed_T(bb):
+    key = bb._weights_key()
+    if getattr(bb, '_streamT_key', None) != key:
+        bb._streamT = pack_stream_T(bb)
+        bb._streamT_key = key
+    return bb._streamT
+
+
 def _packed(bb):
     key = bb._weights_key()
     if getattr(bb, '_stream_key', None) != key:
@@ -230,7 +252,7 @@ def forward_bf16_layers(bb, seq, tbias, tb_stride, work=None):
     h = [buf('h0', torch.bfloat16, B, L, ops.C), buf('h1', torch.bfloat16, B, L, ops.C)]
     fp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
     vec = st['vecs']                               # [(n+1)*3, 128]: see pack_stream
-    _lib.call('drk_ln_fwd_bf16', fp(feat), fp(tbias[0, 0]), tb_stride, fp(vec[1]), fp(vec[2]), _bf16_ptr(h[0], 'h'), B, L,
+    _lib.call('drk_ln_fwd_bf16', fp(feat), fp(tbias[0, 0]), tb_stride, fp(vec[1]), fp(vec[2]), _bf16_ptr(h[0], 'h'), None, None, B, L,
               ops._stream())
     flop = 2.0 * B * L * 9 * ops.C * ops.C
     for i in range(n):
@@ -238,9 +260,9 @@ def forward_bf16_layers(bb, seq, tbias, tb_stride, work=None):
         w_i = st['wstream'][9 * i:]
         args = (_bf16_ptr(h[i & 1], 'h'), fp(feat), fp(feat), _bf16_ptr(h[(i + 1) & 1], 'h_out'), fp(w_i), fp(vec[3 * (i + 1)]),
                 None if last else fp(tbias[0, i + 1]), tb_stride, None if last else fp(vec[3 * (i + 1) + 1]),
-                None if last else fp(vec[3 * (i + 1) + 2]), B, L, 9, bb.dilation(i), 0 if last else 1, ops._stream())
+                None if last else fp(vec[3 * (i + 1) + 2]), B, L, 9, bb.dilation(i), 0 if last else 1, 1, None, None, None, ops._stream())
         ops.PROFILE.bracket('k_layer_bf16', flop, lambda: _lib.call('drk_layer_bf16', *args))
     y = buf('y', torch.float32, B, L, ops.C)
     _lib.call('drk_layer_bf16', _bf16_ptr(h[n & 1], 'h'), None, fp(y), None, fp(st['wstream'][9 * n:]), fp(vec[3 * n + 1]),
-              None, 0, None, None, B, L, 1, 0, 0, ops._stream())
+              None, 0, None, None, B, L, 1, 0, 0, 1, None, None, None, ops._stream())
     return ops.head_out_fwd(y, pk['head2_w'], pk['head2_b'], out=buf('logits', torch.float32, B, L, ops.V))

@@ -36,7 +36,7 @@ def ddpm_update_finetune_gradient(model, x, t, dt, copy_flag_temp, return_proces
         sig = sig[:1]                                  # one shared value (all rows are equal)
     if seed is None and uniforms is None:
         seed = model._draw_seed()
-    logits = autograd.backbone_with_grad(model.backbone, x, sig)
+    logits = autograd.backbone_with_grad(model.backbone, x, sig, model._soft_dtype() == 'bf16')
     x_next, flag = autograd.soft_step_with_grad(logits, x, float(mct[0]), float(mcs[0]),
                                                 float(model.config.finetuning.gumbel_softmax_temp), copy_flag_temp,
                                                 seed or 0, step, sample_offset, uniforms, mc_rows)
@@ -60,6 +60,8 @@ def sample_finetune_gradient(model, num_steps=None, eps=1e-5, eval_sp_size=None,
     table, _, _, _ = noise_schedule.step_table(model.noise, num_steps, eps)
     table = table.tolist()
     bb = model.backbone
+    soft_bf16 = model._soft_dtype() == 'bf16'
+    bb.train_dtype = model._soft_dtype()       # Diffusion.forward (the KL term of the fine-tune loop) follows it
     x = torch.full((batch, L), model.mask_index, dtype=torch.int64, device=dev)      # _sample_prior, on the device
     last_x_list, condt_list, move_chance_t_list, copy_flag_list = [], [], [], []
     # raw logits (with their graph) of every soft step, keyed by the identity of the state they were computed from: the
@@ -100,7 +102,7 @@ def sample_finetune_gradient(model, num_steps=None, eps=1e-5, eval_sp_size=None,
             if x.ndim == 2:
                 x = F.one_hot(x, num_classes=model.vocab_size).to(torch.float32)
             sig = torch.full((1,), sigma_t if model.time_conditioning else 0.0, dtype=torch.float32, device=dev)
-            logits = autograd.backbone_with_grad(bb, x, sig)
+            logits = autograd.backbone_with_grad(bb, x, sig, soft_bf16)
             last_x = x
             model._soft_logits_cache[id(x)] = (x, logits, bb._weights_key())
             x, copy_flag = autograd.soft_step_with_grad(logits, x, mc_t, mc_s, temp, copy_flag_temp, seed, i,

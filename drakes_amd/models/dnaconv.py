@@ -83,6 +83,8 @@ class CNNModel(nn.Module):
         self._packed_key = None
         self._stream = None
         self._stream_key = None
+        self._streamT = None
+        self._streamT_key = None
 
     def packed(self):
         """Kernel-layout copies of the weights; rebuilt when any parameter changed in place
@@ -150,6 +152,6 @@ class CNNModel(nn.Module):
             seq = seq.long()
         if torch.is_grad_enabled() and (seq.requires_grad or any(p.requires_grad for p in self.parameters())):
             from ..autograd import backbone_with_grad
-            return backbone_with_grad(self, seq.contiguous(), t.to(torch.float32))
+            return backbone_with_grad(self, seq.contiguous(), t.to(torch.float32), getattr(self, 'train_dtype', 'fp32') == 'bf16')
         tbias = self.time_bias(t.to(torch.float32))
         return self.forward_f32(seq.contiguous(), tbias, tbias.stride(0))

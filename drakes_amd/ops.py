@@ -210,12 +210,16 @@ def colsum128(x, n_seg, seg_rows, out):
     return out
 
 
-def ln_bwd(dh, feat, tbias_layer, tb_stride, gamma, mean, rstd, g_resid, dxin, dfeat, dgamma, dbeta, dtb_shared=None):
+def ln_bwd(dh, feat, tbias_layer, tb_stride, gamma, mean, rstd, g_resid, dxin, dfeat, dgamma, dbeta, dtb_shared=None,
+           next_mask=None, dc_next=None, dbias_next=None):
+    """dxin may be None (not stored).  next_mask / dc_next / dbias_next: the fused hand-over to the layer below (bf16
+    path): dc_next = bf16(dfeat * next_mask), dbias_next += its column sums."""
     B, L, _ = feat.shape
     tb = ctypes.c_void_p(tbias_layer.data_ptr()) if tbias_layer is not None else None
     _lib.call('drk_ln_bwd', _f(dh, 'dh'), _f(feat, 'feat'), tb, tb_stride, _f(gamma, 'gamma'), _f(mean, 'mean'),
               _f(rstd, 'rstd'), _f(g_resid, 'g_resid'), _f(dxin, 'dxin'), _f(dfeat, 'dfeat'), _f(dgamma, 'dgamma'),
-              _f(dbeta, 'dbeta'), _f(dtb_shared, 'dtbias_shared'), B, L, _stream())
+              _f(dbeta, 'dbeta'), _f(dtb_shared, 'dtbias_shared'), _dev_ptr(next_mask, torch.uint8, 'next_mask'),
+              _dev_ptr(dc_next, torch.bfloat16, 'dc_next'), _f(dbias_next, 'dbias_next'), B, L, _stream())
 
 
 _WORKSPACE = {}
@@ -261,11 +265,12 @@ def stem_bwd(dpre, x, w_t, dw_t, dx):
                   _f(dx, 'dx'), B, L, _stream())
 
 
-def time_bwd(dtbias, sigma, W, temb, dense_w, d_dense_w, d_dense_b, d_lin_w, d_lin_b):
+def time_bwd(dtbias, sigma, W, temb, dense_w, d_dense_w, d_dense_b, d_lin_w, d_lin_b, dtemb):
+    """dtemb: zeroed float32 [nb,128] scratch."""
     nb, n_layers = dtbias.shape[0], dtbias.shape[1]
     _lib.call('drk_time_bwd', _f(dtbias, 'dtbias'), _f(sigma, 'sigma'), nb, _f(W, 'W'), _f(temb, 'temb'),
               _f(dense_w, 'dense_w'), n_layers, _f(d_dense_w, 'd_dense_w'), _f(d_dense_b, 'd_dense_b'),
-              _f(d_lin_w, 'd_lin_w'), _f(d_lin_b, 'd_lin_b'), _stream())
+              _f(d_lin_w, 'd_lin_w'), _f(d_lin_b, 'd_lin_b'), _f(dtemb, 'dtemb'), _stream())
 
 
 def subs_bwd(logits, x, dlogp, out=None):
@@ -301,6 +306,57 @@ def reverse_step_soft_bwd(logits, x_soft, grad_x_next, grad_flag, mc_t, mc_s, te
               float(mc_t), float(mc_s), _mc_rows(mc_rows, B, 2), float(temp),
               float(copy_flag_temp) if copy_flag_temp is not None else 0.0, seed, step, sample_offset, _stream())
     return dlogits, dx
+
+
+# ---- bf16 layer / backward ops (the differentiable bf16 path) ------------------------------------------
+def _b16(t, name):
+    return _dev_ptr(t, torch.bfloat16, name)
+
+
+def _raw(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def ln_fwd_bf16(feat, tbias_layer, tb_stride, gamma, beta, out=None, mean=None, rstd=None):
+    """h = bf16(LayerNorm(feat + tbias) * gamma + beta); optional mean / rstd [B*L] for the backward pass."""
+    B, L, _ = feat.shape
+    out = out if out is not None else torch.empty(B, L, C, dtype=torch.bfloat16, device=feat.device)
+    _lib.call('drk_ln_fwd_bf16', _f(feat, 'feat'), _raw(tbias_layer), tb_stride, _f(gamma, 'gamma'), _f(beta, 'beta'),
+              _b16(out, 'h'), _f(mean, 'mean'), _f(rstd, 'rstd'), B, L, _stream())
+    return out
+
+
+def layer_bf16(h, wfrag, feat_out, *, feat=None, h_out=None, bias=None, tbias=None, tb_stride=0, gamma=None, beta=None,
+               taps=9, dilation=1, relu=True, relu_mask=None, mean=None, rstd=None):
+    """One launch of drk_layer_bf16 (see include/drakes_hip.h).  wfrag: a view into the packed fragment stream that
+    starts at this layer's first tap.  ln is on when gamma is given."""
+    B, L, _ = h.shape
+    _lib.call('drk_layer_bf16', _b16(h, 'h'), _f(feat, 'feat'), _f(feat_out, 'feat_out'), _b16(h_out, 'h_out'),
+              _b16(wfrag, 'wfrag'), _raw(bias), _raw(tbias), tb_stride, _raw(gamma), _raw(beta), B, L, taps, dilation,
+              1 if gamma is not None else 0, 1 if relu else 0, _dev_ptr(relu_mask, torch.uint8, 'relu_mask'),
+              _f(mean, 'mean'), _f(rstd, 'rstd'), _stream())
+    return feat_out
+
+
+def gate_bf16(g, relu_mask=None, y=None, colsum=None, out=None):
+    """out = bf16(g * gate), gate = relu_mask (uint8) or (y > 0); colsum [128] += column sums (deterministic)."""
+    B, L, _ = g.shape
+    out = out if out is not None else torch.empty(B, L, C, dtype=torch.bfloat16, device=g.device)
+    ws = workspace(_lib.load().drk_gate_bf16_workspace_bytes(), g.device) if colsum is not None else None
+    _lib.call('drk_gate_bf16', _f(g, 'g'), _dev_ptr(relu_mask, torch.uint8, 'relu_mask'), _f(y, 'y'), _b16(out, 'out'),
+              _f(colsum, 'colsum'), B, L, _f(ws, 'workspace'), ws.numel() * 4 if ws is not None else 0, _stream())
+    return out
+
+
+def conv_wgrad_bf16(h, dc, dwt, dilation, ws=None):
+    """dwt [taps,128(ci),128(co)] += sum_rows h[row + off][ci] * dc[row][co] from bf16 operands (fp32 accumulation,
+    deterministic split-K through the workspace)."""
+    B, L, _ = h.shape
+    taps = dwt.shape[0]
+    if ws is None:
+        ws = workspace(_lib.load().drk_conv_wgrad_bf16_workspace_bytes(B, L, taps), h.device)
+    _lib.call('drk_conv_wgrad_bf16', _b16(h, 'h'), _b16(dc, 'dc'), _f(dwt, 'dwt'), B, L, taps, dilation, _f(ws, 'workspace'),
+              ws.numel() * 4, _stream())
 
 
 # ---- weight layouts the kernels read (pure index permutations) --------------------------------

@@ -151,12 +151,15 @@ int drk_mask_mul(const float* g, const unsigned char* mask, float* out, long n, 
 int drk_relu_bwd(const float* g, const float* y, float* out, long n, void* stream);
 /* out[seg][128] += column sums of x[seg*seg_rows .. +seg_rows][128] (bias / time-bias gradients). */
 int drk_colsum128(const float* x, float* out, long n_seg, long seg_rows, void* stream);
-/* LayerNorm backward of drk_ln_fwd: dxin, dfeat = dxin + g_resid (g_resid may be NULL), dgamma/dbeta accumulated;
- * dtbias_shared (optional, float32 [128], accumulated): the column sum of dxin = the gradient of a time bias that one
- * row serves the whole batch with (tbias_bstride == 0). */
+/* LayerNorm backward of drk_ln_fwd: dxin (optional output), dfeat = dxin + g_resid (g_resid may be NULL), dgamma/dbeta
+ * accumulated; dtbias_shared (optional, float32 [128], accumulated): the column sum of dxin = the gradient of a time bias
+ * that one row serves the whole batch with (tbias_bstride == 0).  Optional fused hand-over to the layer below (the bf16
+ * path): next_mask = that layer's ReLU mask (uint8 [B*L][128]), dc_next = bf16(dfeat * next_mask) (bf16 [B*L][128]),
+ * dbias_next (float32 [128], accumulated) = its column sums, the conv bias gradient. */
 int drk_ln_bwd(const float* dh, const float* feat, const float* tbias, long tbias_bstride, const float* gamma,
                const float* mean, const float* rstd, const float* g_resid, float* dxin, float* dfeat,
-               float* dgamma, float* dbeta, float* dtbias_shared, int B, int L, void* stream);
+               float* dgamma, float* dbeta, float* dtbias_shared, const unsigned char* next_mask, void* dc_next,
+               float* dbias_next, int B, int L, void* stream);
 /* Conv1d weight gradient: dwt[t][ci][co] += sum_rows h[row + (t - taps/2)*dilation][ci] * dc[row][co].  dbias (optional, float32 [128], accumulated): column sums of dc,
  * the conv bias gradient, taken by the centre-tap workgroups on the way.  Deterministic split-K: every (row chunk, tap)
  * workgroup stores its 128x128 partial into `workspace` (device memory, 16-byte aligned, at least
@@ -180,10 +183,11 @@ int drk_head_out_bwd(const float* dlogits, const float* y, const float* w, float
  * (NULL for token input: no gradient flows into integer tokens). */
 int drk_stem_bwd(const float* dpre, const int64_t* x, const float* x_soft, const float* w_t, float* dw_t,
                  float* dx, int B, int L, void* stream);
-/* Backward of drk_time_bias_fwd + drk_time_embed_fwd from dtbias [nb][n_layers][128]; all outputs accumulated. */
+/* Backward of drk_time_bias_fwd + drk_time_embed_fwd from dtbias [nb][n_layers][128]; all outputs accumulated.
+ * dtemb: float32 [nb][128] scratch, ZEROED by the caller (the layers' contributions to the embedding gradient meet there). */
 int drk_time_bwd(const float* dtbias, const float* sigma, int nb, const float* W, const float* temb,
                  const float* dense_w, int n_layers, float* d_dense_w, float* d_dense_b, float* d_lin_w,
-                 float* d_lin_b, void* stream);
+                 float* d_lin_b, float* dtemb, void* stream);
 /* Backward of drk_subs_fwd: rows holding a token are constants (dlogits = 0), :250-252. */
 int drk_subs_bwd(const float* logits, const int64_t* x, const float* x_soft, const float* dlogp, float* dlogits,
                  int B, int L, void* stream);
@@ -244,19 +248,41 @@ int drk_sample_bf16(const void* wstream, const void* stem_w, const void* head2_w
                     signed char* traj_out, float* logits_out, int dump_fwd, float* dbg_feat, int dbg_layer, int B, int L, int num_steps, int n_layers,
                     const int* dilations, int noise_removal, uint64_t seed, uint64_t sample_offset, int flags, void* stream);
 
-/* ---- one residual layer per launch, bf16 MFMA (any L; BASELINE.json configs[4]: 1024-bp sequences) ---------------
+/* ---- one residual layer per launch, bf16 MFMA (any L; BASELINE.json configs[4]: 1024-bp sequences; and the
+ * differentiable bf16 path of _sample_finetune_gradient, diffusion_gosai_update.py:552-630) ----------------------------
  * models/dnaconv.py:88-97 for one layer:  feat_out = feat + relu(conv_dilated(h) + bias)   (feat NULL: no residual — the
  * head's final_conv.0, :104), and, when h_out is not NULL, the NEXT layer's input
  * h_out = bf16(LayerNorm(feat_out + tbias) * gamma + beta) (ln = 1) or bf16(feat_out) (ln = 0).
  * h, h_out: bf16 [B*L][128], distinct buffers (neighbouring workgroups read h while h_out is written);
  * feat, feat_out: float32 [B*L][128] (may alias); wfrag: this layer's taps in the fragment order of
- * drakes_amd/fastpath.py::pack_stream; tbias: [128] of batch row 0, tb_stride floats between rows (0: shared). */
+ * drakes_amd/fastpath.py::pack_stream; tbias: [128] of batch row 0, tb_stride floats between rows (0: shared).
+ * For the backward pass (all optional): relu_mask uint8 [B*L][128] = (pre-activation > 0); mean, rstd float32 [B*L] =
+ * the statistics of that next LayerNorm.  relu = 0 with bias = NULL, feat = NULL, h_out = NULL is the convolution's
+ * INPUT GRADIENT: h = dc (bf16), wfrag = the stream packed from weight.transpose(0,1).flip(2), feat_out = dh. */
 int drk_layer_bf16(const void* h, const float* feat, float* feat_out, void* h_out, const void* wfrag, const float* bias,
                    const float* tbias, long tb_stride, const float* gamma, const float* beta, int B, int L, int taps,
-                   int dilation, int ln, void* stream);
-/* h = bf16(LayerNorm(feat + tbias) * gamma + beta): the first layer's input (dnaconv.py:92-93). */
+                   int dilation, int ln, int relu, unsigned char* relu_mask, float* mean, float* rstd, void* stream);
+/* h = bf16(LayerNorm(feat + tbias) * gamma + beta): the first layer's input (dnaconv.py:92-93); mean, rstd: optional
+ * float32 [B*L] outputs for the backward pass. */
 int drk_ln_fwd_bf16(const float* feat, const float* tbias, long tb_stride, const float* gamma, const float* beta, void* h,
-                    int B, int L, void* stream);
+                    float* mean, float* rstd, int B, int L, void* stream);
+
+/* ---- bf16 backward of the denoiser (the differentiable bf16 path; reference: torch autograd over
+ * models/dnaconv.py:88-101 inside _sample_finetune_gradient, diffusion_gosai_update.py:589-630) ----------------------
+ * The convolution's INPUT gradient is drk_layer_bf16 (relu = 0) on the transposed, tap-flipped stream. */
+/* dc = bf16(g * gate): g float32 [B*L][128]; gate = relu_mask (uint8 [B*L][128] from drk_layer_bf16 / drk_conv_fwd_f32) or
+ * (y > 0) for a saved ReLU output y (exactly one of the two non-NULL); out bf16 [B*L][128].  colsum (optional, float32
+ * [128], accumulated): column sums of the fp32 products = the conv bias gradient, reduced in a fixed order through
+ * `workspace` (drk_gate_bf16_workspace_bytes() bytes, 16-byte aligned). */
+long drk_gate_bf16_workspace_bytes(void);
+int drk_gate_bf16(const float* g, const unsigned char* relu_mask, const float* y, void* out, float* colsum, int B, int L,
+                  void* workspace, long workspace_bytes, void* stream);
+/* Conv1d weight gradient from bf16 operands: dwt[t][ci][co] += sum_rows h[row + (t - taps/2)*dilation][ci] * dc[row][co],
+ * h, dc bf16 [B*L][128], dwt float32 [taps][128][128]; fp32 accumulation.  Deterministic split-K as drk_conv_wgrad_f32:
+ * `workspace` holds one 64-KB slab per (row chunk, tap), drk_conv_wgrad_bf16_workspace_bytes(B, L, taps) bytes. */
+long drk_conv_wgrad_bf16_workspace_bytes(int B, int L, int taps);
+int drk_conv_wgrad_bf16(const void* h, const void* dc, float* dwt, int B, int L, int taps, int dilation, void* workspace,
+                        long workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

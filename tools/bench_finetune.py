@@ -23,6 +23,7 @@ def loop(a):
     torch.manual_seed(0)
     cfg = drakes_amd.default_config(length=a.length, steps=a.steps, truncate_steps=a.trunc)
     new_model, old_model = drakes_amd.Diffusion(cfg).to(dev), drakes_amd.Diffusion(cfg).to(dev)
+    new_model.hip_dtype = old_model.hip_dtype = a.dtype
     old_model.load_state_dict(new_model.state_dict())
     reward = torch.nn.Sequential(torch.nn.Conv1d(4, 8, 5, padding=2), torch.nn.Tanh(), torch.nn.AdaptiveAvgPool1d(1),
                                  torch.nn.Flatten(), torch.nn.Linear(8, 3), torch.nn.Unflatten(1, (3, 1))).to(dev)
@@ -40,7 +41,7 @@ def loop(a):
         ts.append(time.perf_counter() - t0)
         print(f'rep {r}: {ts[-1]:.3f} s per optimizer step', flush=True)
     res = {'workload': f'fine_tune optimizer step: _sample_finetune_gradient (K={a.trunc}) + reward + KL over all {a.steps} '
-                       f'steps (new + frozen model) + backward + clip + Adam, batch {a.batch}, L={a.length}, fp32 kernels',
+                       f'steps (new + frozen model) + backward + clip + Adam, batch {a.batch}, L={a.length}, {a.dtype} kernels',
            'seconds_per_step': sorted(ts[1:])[len(ts[1:]) // 2], 'peak_mem_GiB': torch.cuda.max_memory_allocated() / 2 ** 30}
     print(json.dumps(res), flush=True)
     if a.json:
@@ -56,6 +57,7 @@ def main():
     ap.add_argument('--length', type=int, default=200)
     ap.add_argument('--reps', type=int, default=3)
     ap.add_argument('--json', default=None)
+    ap.add_argument('--dtype', default='fp32', choices=['fp32', 'bf16'], help="hip_dtype: 'bf16' = fused hard phase + bf16 soft steps and backward")
     ap.add_argument('--loop', action='store_true', help='time whole fine_tune optimizer steps (sampling + reward + KL over all steps + Adam)')
     a = ap.parse_args()
     if a.loop:
@@ -64,6 +66,7 @@ def main():
     torch.manual_seed(0)
     cfg = drakes_amd.default_config(length=a.length, steps=a.steps, truncate_steps=a.trunc)
     m = drakes_amd.Diffusion(cfg).to(dev).train()
+    m.hip_dtype = a.dtype
     rw = torch.randn(a.batch, 4, a.length, device=dev)
     fwd, bwd = [], []
     for r in range(a.reps + 1):
@@ -83,7 +86,7 @@ def main():
         print(f'rep {r}: forward {t1 - t0:.3f} s, backward {t2 - t1:.3f} s', flush=True)
     gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m.parameters() if p.grad is not None)).item()
     res = {'workload': f'configs[2]: _sample_finetune_gradient + backward, batch {a.batch}, L={a.length}, {a.steps} steps, '
-                       f'K={a.trunc}, fp32 kernels', 'forward_s': sorted(fwd)[len(fwd) // 2], 'backward_s': sorted(bwd)[len(bwd) // 2],
+                       f'K={a.trunc}, {a.dtype} kernels', 'forward_s': sorted(fwd)[len(fwd) // 2], 'backward_s': sorted(bwd)[len(bwd) // 2],
            'total_s': sorted(f + b for f, b in zip(fwd, bwd))[len(fwd) // 2],
            'peak_mem_GiB': torch.cuda.max_memory_allocated() / 2 ** 30, 'grad_norm': gn}
     print(json.dumps(res), flush=True)

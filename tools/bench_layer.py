@@ -29,7 +29,7 @@ flop = 2.0 * B * L * 9 * 128 * 128
 byts = B * L * (256 + 512 + 512 + 256)
 for i, d in ((0, 1), (2, 4), (3, 16), (4, 64)):
     args = (P(h0), P(feat), P(feat), P(h1), P(st['wstream'][9 * i:]), P(vec[3 * (i + 1)]), P(tbias[0, i + 1]), 0,
-            P(vec[3 * (i + 1) + 1]), P(vec[3 * (i + 1) + 2]), B, L, 9, d, 1, ops._stream())
+            P(vec[3 * (i + 1) + 1]), P(vec[3 * (i + 1) + 2]), B, L, 9, d, 1, 1, None, None, None, ops._stream())
     for _ in range(3):
         _lib.call('drk_layer_bf16', *args)
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.reps)]
