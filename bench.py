@@ -48,13 +48,14 @@ PEAK = {'bf16': 2500.0, 'fp32': 157.3}            # TFLOP/s dense MFMA, MI355X_M
 # for 16-B-per-lane loads on gfx950): tools/pmc_traffic.sh.  A recorded measurement (a process cannot collect PMC
 # counters on itself): it names the library version it was taken on and is printed ONLY when drk_version() still is
 # that version — a changed kernel reports traffic null until the passes are re-run.
-PMC_TRAFFIC = {('bf16', 1024): {'drk_version': 109,
-                                'bytes_per_launch': 26392558656.0, 'fetch_bytes': 26173237760.0, 'write_bytes': 219320896.0,
+PMC_TRAFFIC = {('bf16', 1024): {'drk_version': 201,
+                                'bytes_per_launch': 27219483200.0, 'fetch_bytes': 26716479232.0, 'write_bytes': 503003968.0,
                                 'algorithmic_bytes': 7.6e6,
                                 'note': 'L2-to-fabric requests; Infinity-Cache hits are counted: the 5.9 MB bf16 weight '
                                         'stream outgrows a 4 MB per-XCD L2 and is re-fetched from the 256 MB Infinity '
-                                        'Cache; 0.24 TB/s = 2.9 % of HBM peak, the launch is MFMA-bound',
-                                'source': 'profiles/r1_bf16_v8_pmc_traffic.json'}}
+                                        'Cache; 0.25 TB/s = 3.1 % of HBM peak, the launch is MFMA-bound; the writes are '
+                                        'scratch spills of the per-forward stem/head block (152 B/lane), tokens out are 1.6 MB',
+                                'source': 'profiles/r2_bf16_v10_pmc_traffic.json'}}
 
 
 def _median(v):
@@ -123,26 +124,48 @@ def spawn_ranks(n):
     return rc
 
 
+class _stdout_to_stderr:
+    """RCCL prints a version banner on the C stdout when its first communicator comes up; the contract is ONE JSON line
+    on stdout, so file descriptor 1 points at stderr while a process group is being created and first used."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)          # C stdio buffers of the libraries that printed
+        except Exception:
+            pass
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+
+
 def _rccl_world1_probe(dev):
     """N=1: join an 'nccl' (RCCL) group of one rank and push (a) a one, (b) a gradient-bucket-sized fp32 tensor through
     all_reduce, so that the library the N>1 runs depend on is loaded and exercised on this box too."""
     import torch.distributed as dist
     info = {'backend': 'nccl', 'world': 1}
     try:
-        dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{_free_port()}', rank=0, world_size=1, device_id=dev)
-        one = torch.ones(1, device=dev)
-        dist.all_reduce(one)
-        info['ranks_seen'] = int(one.item())
-        flat = torch.ones(3326597, dtype=torch.float32, device=dev)     # the fine-tune gradient bucket (13.3 MB)
-        dist.all_reduce(flat)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(5):
+        with _stdout_to_stderr():
+            dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{_free_port()}', rank=0, world_size=1,
+                                    device_id=dev)
+            one = torch.ones(1, device=dev)
+            dist.all_reduce(one)
+            info['ranks_seen'] = int(one.item())
+            flat = torch.ones(3326597, dtype=torch.float32, device=dev)     # the fine-tune gradient bucket (13.3 MB)
             dist.all_reduce(flat)
-        torch.cuda.synchronize()
-        info['allreduce_13MB_us'] = (time.perf_counter() - t0) / 5 * 1e6
-        info['ok'] = bool(flat[0].item() == 1.0)
-        dist.destroy_process_group()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                dist.all_reduce(flat)
+            torch.cuda.synchronize()
+            info['allreduce_13MB_us'] = (time.perf_counter() - t0) / 5 * 1e6
+            info['ok'] = bool(flat[0].item() == 1.0)
+            dist.destroy_process_group()
     except Exception as e:                              # a box without a usable RCCL must not lose the bench line
         info['ok'] = False
         info['error'] = f'{type(e).__name__}: {e}'[:300]
@@ -316,12 +339,14 @@ def main():
     collective = {'backend': backend, 'world': world}
     if world > 1:
         import torch.distributed as dist
-        if backend == 'nccl':
-            dist.init_process_group('nccl', device_id=dev)        # RCCL over xGMI
-        else:
-            dist.init_process_group(backend)
-        ones = torch.ones(1, device=dev if backend == 'nccl' else 'cpu')
-        dist.all_reduce(ones)
+        with _stdout_to_stderr():
+            if backend == 'nccl':
+                dist.init_process_group('nccl', device_id=dev)        # RCCL over xGMI
+            else:
+                dist.init_process_group(backend)
+            ones = torch.ones(1, device=dev if backend == 'nccl' else 'cpu')
+            dist.all_reduce(ones)
+            torch.cuda.synchronize()
         collective['ranks_seen'] = int(ones.item())
         if shared_device:
             collective['note'] = f'{world} ranks share {n_dev} GPU(s): rehearsal, RCCL needs one device per rank'
@@ -367,8 +392,9 @@ def main():
         line['collective'] = collective
         print(json.dumps(line), flush=True)
     if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        with _stdout_to_stderr():
+            dist.barrier()
+            dist.destroy_process_group()
 
 
 if __name__ == '__main__':
