@@ -32,6 +32,15 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 #define LT_SUB_BYTES 1024
 #define LT_PART_STRIDE 12        // floats per row in the LayerNorm partial buffer (8 used)
 
+// -DLT_STAMPS (tools/layer_stamps.py, never in the shipped library): thread 0 of every workgroup leaves wall-clock and
+// shader-clock stamps of its phases in the mean / rstd outputs, which then hold no statistics.
+#ifdef LT_STAMPS
+#define LT_STAMP(i) do { if (threadIdx.x == 0) { ((unsigned long long*)a.mean_out)[blockIdx.x * 8 + (i)] = wall_clock64(); \
+    ((unsigned long long*)a.rstd_out)[blockIdx.x * 8 + (i)] = clock64(); } } while (0)
+#else
+#define LT_STAMP(i) do { } while (0)
+#endif
+
 struct LayerArgs {
   const char* h;            // bf16 [M][128]
   const float* feat;        // fp32 [M][128] residual input (NULL: no residual, head conv)
@@ -83,6 +92,7 @@ __global__ void __launch_bounds__(256, WGS) k_layer_bf16(const LayerArgs a) {
     acc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f};
     acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
+  LT_STAMP(0);
   const int center = a.taps / 2;
   const int last_tap = a.taps - 1 - a.first_tap;          // live taps: first_tap .. taps-1-first_tap (shift < L)
   const char* wlane = a.wfrag + ct * (2 * LT_SUB_BYTES) + lane * 16;
@@ -113,6 +123,7 @@ __global__ void __launch_bounds__(256, WGS) k_layer_bf16(const LayerArgs a) {
       }
     }
     __syncthreads();
+    LT_STAMP(1);
     // the fp32 residual of this lane's outputs: in flight under the whole tap loop
 #pragma unroll
     for (int t = 0; t < (PRE ? LT_NT : 0); ++t) {
@@ -220,6 +231,7 @@ __global__ void __launch_bounds__(256, WGS) k_layer_bf16(const LayerArgs a) {
   }
 
   // ---- epilogue ---------------------------------------------------------------------------------------------------
+  LT_STAMP(2);
   {
 #pragma clang fp contract(fast)
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -251,6 +263,7 @@ __global__ void __launch_bounds__(256, WGS) k_layer_bf16(const LayerArgs a) {
       x[t][s] = r;
     }
   }
+  LT_STAMP(3);
   if (!a.h_out) return;
   __syncthreads();   // every wave is past its reads of the activation tiles: tile[0] becomes the h' staging area
   if (a.ln) {
@@ -284,6 +297,7 @@ __global__ void __launch_bounds__(256, WGS) k_layer_bf16(const LayerArgs a) {
     const f32x4 g0 = *(const f32x4*)(a.gamma + ch0), g1 = *(const f32x4*)(a.gamma + ch0 + 16);
     const f32x4 b0 = *(const f32x4*)(a.beta + ch0), b1 = *(const f32x4*)(a.beta + ch0 + 16);
     __syncthreads();
+    LT_STAMP(4);
 #pragma unroll
     for (int t = 0; t < LT_NT; ++t) {
       const float* pp = part + (16 * t + pn) * LT_PART_STRIDE;
@@ -294,10 +308,12 @@ __global__ void __launch_bounds__(256, WGS) k_layer_bf16(const LayerArgs a) {
       const float var = fmaxf(s2 * (1.0f / 128.0f) - mean * mean, 0.0f);
       const float rstd = __builtin_amdgcn_rsqf(var + 1e-5f);
       const float c = -mean * rstd;
+#ifndef LT_STAMPS
       if (a.mean_out && ct == 0 && g == 0 && r0 + 16 * t + pn < a.M) {
         a.mean_out[r0 + 16 * t + pn] = mean;
         a.rstd_out[r0 + 16 * t + pn] = rstd;
       }
+#endif
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         x[t][0][i] = (x[t][0][i] * rstd + c) * g0[i] + b0[i];
@@ -322,6 +338,17 @@ __global__ void __launch_bounds__(256, WGS) k_layer_bf16(const LayerArgs a) {
     const long row = r0 + srow + 16 * i;
     if (row < a.M) *(f32x4*)(a.h_out + row * 256 + 16 * scol) = *(const f32x4*)(tile0 + (srow + 16 * i) * LT_ROWB + 16 * scol);
   }
+  LT_STAMP(5);
+#ifdef LT_STAMPS
+  __builtin_amdgcn_s_waitcnt(0);
+  LT_STAMP(6);
+  if (threadIdx.x == 0) {
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    ((unsigned long long*)a.mean_out)[blockIdx.x * 8 + 7] = ((unsigned long long)xcc << 32) | hw;
+  }
+#endif
   }
 }
 
