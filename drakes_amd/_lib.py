@@ -32,12 +32,12 @@ SIGNATURES = {
     'drk_time_embed_fwd': [_P, c_int, _P, _P, _P, _P, _P],
     'drk_time_bias_fwd': [_P, c_int, _P, _P, c_int, _P, _P],
     'drk_stem_fwd': [_P, _P, _P, _P, _P, c_int, c_int, _P],
-    'drk_ln_fwd': [_P, _P, c_long, _P, _P, _P, _P, _P, c_int, c_int, _P],
+    'drk_ln_fwd': [_P, _P, c_long, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P],
     'drk_conv_fwd_f32': [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P],
     'drk_mask_mul': [_P, _P, _P, c_long, _P],
     'drk_relu_bwd': [_P, _P, _P, c_long, _P],
     'drk_colsum128': [_P, _P, c_long, c_long, _P],
-    'drk_ln_bwd': [_P, _P, _P, c_long, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P],
+    'drk_ln_bwd': [_P, _P, _P, c_long, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P],
     'drk_conv_wgrad_f32': [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, c_long, _P],
     'drk_conv_wgrad_f32_static': [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P],
     'drk_head_out_bwd': [_P, _P, _P, _P, _P, _P, c_int, c_int, _P],

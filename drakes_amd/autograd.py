@@ -60,7 +60,7 @@ class _BackboneFn(torch.autograd.Function):
         for i in range(n):
             mean = torch.empty(B * L, dtype=torch.float32, device=seq.device)
             rstd = torch.empty_like(mean)
-            ops.ln_fwd(feats[i], tbias[0, i], tb_stride, pk['ln_g'][i], pk['ln_b'][i], out=h, mean=mean, rstd=rstd)
+            ops.ln_fwd(feats[i], tbias[0, i], tb_stride, pk['ln_g'][i], pk['ln_b'][i], out=h, mean=mean, rstd=rstd, width=bb.width)
             mask = torch.empty(B, L, C, dtype=torch.uint8, device=seq.device)
             feats.append(ops.conv_fwd_f32(h, pk['conv_w'][i], pk['conv_b'][i], feats[i], bb.dilation(i), relu=True,
                                           relu_mask=mask))
@@ -105,7 +105,7 @@ class _BackboneFn(torch.autograd.Function):
             d = bb.dilation(i)
             ops.mask_mul(gr, masks[i], out=dc)
             if want_w:
-                ops.ln_fwd(feats[i], ctx.tbias[0, i], ctx.tb_stride, pk['ln_g'][i], pk['ln_b'][i], out=h)
+                ops.ln_fwd(feats[i], ctx.tbias[0, i], ctx.tb_stride, pk['ln_g'][i], pk['ln_b'][i], out=h, width=bb.width)
                 dwt, dbias = zeros(9, C, C), zeros(C)
                 ops.conv_wgrad_f32(h, dc, dwt, d, dbias)          # the bias gradient rides on the centre tap
                 g[f'convs.{i}.weight'], g[f'convs.{i}.bias'] = dwt.permute(2, 1, 0), dbias
@@ -114,7 +114,7 @@ class _BackboneFn(torch.autograd.Function):
             gnew = torch.empty_like(y)
             shared_tb = want_w and not ctx.tb_stride          # one time-bias row for the batch: its gradient is fused in
             ops.ln_bwd(dh, feats[i], ctx.tbias[0, i], ctx.tb_stride, pk['ln_g'][i], means[i], rstds[i], gr, dxin, gnew,
-                       dgam, dbet, dtb[i, 0] if shared_tb else None)
+                       dgam, dbet, dtb[i, 0] if shared_tb else None, width=bb.width)
             g[f'norms.{i}.weight'], g[f'norms.{i}.bias'] = dgam, dbet
             if want_w and ctx.tb_stride:
                 ops.colsum128(dxin, B, L, dtb[i])
@@ -138,7 +138,8 @@ class _BackboneFn(torch.autograd.Function):
         g['time_embedder.1.weight'], g['time_embedder.1.bias'] = d_lin_w, d_lin_b
         for i in range(n):
             g[f'time_layers.{i}.dense.weight'], g[f'time_layers.{i}.dense.bias'] = d_dense_w[i], d_dense_b[i]
-        grads = [g.get(k) if ctx.needs_input_grad[3 + j] else None for j, k in enumerate(ctx.names)]
+        # (a model narrower than the kernels' 128 lanes: its gradients are the leading slices of the padded ones)
+        grads = [bb.narrow(k, g.get(k)) if ctx.needs_input_grad[3 + j] else None for j, k in enumerate(ctx.names)]
         ctx.feats = ctx.masks = ctx.means = ctx.rstds = ctx.y = None
         return (None, dseq if ctx.needs_input_grad[1] else None, None, *grads)
 

@@ -88,7 +88,9 @@ __global__ void __launch_bounds__(256) k_ln_fwd(const float* __restrict__ feat, 
                                                 long tb_stride, const float* __restrict__ gamma,
                                                 const float* __restrict__ beta, float* __restrict__ h,
                                                 float* __restrict__ mean_out, float* __restrict__ rstd_out, long M,
-                                                int L) {
+                                                int L, int width) {
+  // width < 128: a narrower model zero-padded into the 128 lanes (gamma = beta = 0 there): the statistics are taken over
+  // the first `width` channels only; the other lanes hold 0 going in and coming out.
   const int lr = threadIdx.x & 31;
   const long row = (long)blockIdx.x * 8 + (threadIdx.x >> 5);
   if (row >= M) return;
@@ -98,12 +100,14 @@ __global__ void __launch_bounds__(256) k_ln_fwd(const float* __restrict__ feat, 
   float s = (v[0] + v[1]) + (v[2] + v[3]);
 #pragma unroll
   for (int o = 16; o >= 1; o >>= 1) s += __shfl_xor(s, o);
-  const float mean = s * (1.0f / DRK_C);
+  const float inv = 1.0f / (float)width;
+  const float mean = s * inv;
   const f32x4 d = v - mean;
   float q = (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+  if (4 * lr >= width) q = 0.0f;
 #pragma unroll
   for (int o = 16; o >= 1; o >>= 1) q += __shfl_xor(q, o);
-  const float rstd = 1.0f / sqrtf(q * (1.0f / DRK_C) + 1e-5f);
+  const float rstd = 1.0f / sqrtf(q * inv + 1e-5f);
   const f32x4 g = *(const f32x4*)(gamma + 4 * lr), be = *(const f32x4*)(beta + 4 * lr);
   *(f32x4*)(h + row * DRK_C + 4 * lr) = d * rstd * g + be;
   if (mean_out && lr == 0) {
@@ -387,13 +391,14 @@ extern "C" int drk_stem_fwd(const int64_t* x, const float* x_soft, const float* 
 }
 
 extern "C" int drk_ln_fwd(const float* feat, const float* tbias, long tbias_bstride, const float* gamma,
-                          const float* beta, float* h, float* mean, float* rstd, int B, int L, void* stream) {
+                          const float* beta, float* h, float* mean, float* rstd, int B, int L, int width, void* stream) {
   DRK_SHAPE_GUARD("drk_ln_fwd");
   ARGCHECK(feat && gamma && beta && h && B >= 0 && L > 0 && (!mean == !rstd), "drk_ln_fwd");
+  ARGCHECK(width >= 4 && width <= DRK_C && width % 4 == 0, "drk_ln_fwd (width: a multiple of 4 in [4, 128])");
   const long M = (long)B * L;
   if (M == 0) return DRK_OK;
   hipLaunchKernelGGL(k_ln_fwd, dim3((unsigned)((M + 7) / 8)), dim3(256), 0, (hipStream_t)stream, feat, tbias,
-                     tbias_bstride, gamma, beta, h, mean, rstd, M, L);
+                     tbias_bstride, gamma, beta, h, mean, rstd, M, L, width);
   DRK_CHECK_LAUNCH();
   return DRK_OK;
 }

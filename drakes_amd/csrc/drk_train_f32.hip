@@ -69,8 +69,10 @@ __global__ void __launch_bounds__(256) k_ln_bwd(const float* __restrict__ dh, co
                                                 float* __restrict__ dxin, float* __restrict__ dfeat,
                                                 float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                 float* __restrict__ dtb, const unsigned char* __restrict__ next_mask,
-                                                char* __restrict__ dc_next, float* __restrict__ dbias_next, long M, int L) {
+                                                char* __restrict__ dc_next, float* __restrict__ dbias_next, long M, int L,
+                                                int width) {
   __shared__ float pg[8][128], pb[8][128], px[8][128], pc[8][128];
+  const float inv = 1.0f / (float)width;   // width < 128: statistics over the first `width` channels (drk_ln_fwd)
   const int lr = threadIdx.x & 31, sub = threadIdx.x >> 5;
   const f32x4 gm = *(const f32x4*)(gamma + 4 * lr);
   f32x4 ag = {0.f, 0.f, 0.f, 0.f}, ab = {0.f, 0.f, 0.f, 0.f}, ax = {0.f, 0.f, 0.f, 0.f}, ac = {0.f, 0.f, 0.f, 0.f};
@@ -89,8 +91,9 @@ __global__ void __launch_bounds__(256) k_ln_bwd(const float* __restrict__ dh, co
       s1 += __shfl_xor(s1, o);
       s2 += __shfl_xor(s2, o);
     }
-    const float m1 = s1 * (1.0f / DRK_C), m2 = s2 * (1.0f / DRK_C);
-    const f32x4 dx = (dyg - m1 - xh * m2) * rs;
+    const float m1 = s1 * inv, m2 = s2 * inv;
+    f32x4 dx = (dyg - m1 - xh * m2) * rs;
+    if (4 * lr >= width) dx = f32x4{0.f, 0.f, 0.f, 0.f};   // padding lanes carry no gradient
     if (dxin) *(f32x4*)(dxin + row * DRK_C + 4 * lr) = dx;
     f32x4 o = dx;
     if (g_resid) o += *(const f32x4*)(g_resid + row * DRK_C + 4 * lr);
@@ -776,13 +779,14 @@ extern "C" int drk_colsum128(const float* x, float* out, long n_seg, long seg_ro
 extern "C" int drk_ln_bwd(const float* dh, const float* feat, const float* tbias, long tbias_bstride, const float* gamma,
                           const float* mean, const float* rstd, const float* g_resid, float* dxin, float* dfeat,
                           float* dgamma, float* dbeta, float* dtbias_shared, const unsigned char* next_mask, void* dc_next,
-                          float* dbias_next, int B, int L, void* stream) {
+                          float* dbias_next, int B, int L, int width, void* stream) {
   DRK_SHAPE_GUARD("drk_ln_bwd");
+  ARGCHECK(width >= 4 && width <= DRK_C && width % 4 == 0, "drk_ln_bwd (width: a multiple of 4 in [4, 128])");
   ARGCHECK(dh && feat && gamma && mean && rstd && dfeat && dgamma && dbeta, "drk_ln_bwd");
   ARGCHECK((!next_mask && !dc_next && !dbias_next) || (next_mask && dc_next), "drk_ln_bwd (next_mask and dc_next come together)");
   const long M = (long)B * L;
   hipLaunchKernelGGL(k_ln_bwd, dim3((unsigned)((M + 63) / 64)), dim3(256), 0, (hipStream_t)stream, dh, feat, tbias,
-                     tbias_bstride, gamma, mean, rstd, g_resid, dxin, dfeat, dgamma, dbeta, dtbias_shared, next_mask, (char*)dc_next, dbias_next, M, L);
+                     tbias_bstride, gamma, mean, rstd, g_resid, dxin, dfeat, dgamma, dbeta, dtbias_shared, next_mask, (char*)dc_next, dbias_next, M, L, width);
   DRK_CHECK_LAUNCH();
   return DRK_OK;
 }

@@ -84,6 +84,7 @@ def pack_stream_T(bb):
 
 
 def _packed_T(bb):
+    _need_full_width(bb)
     key = bb._weights_key()
     if getattr(bb, '_streamT_key', None) != key:
         bb._streamT = pack_stream_T(bb)
@@ -91,7 +92,14 @@ def _packed_T(bb):
     return bb._streamT
 
 
+def _need_full_width(bb):
+    if getattr(bb, 'width', 128) != 128:
+        raise NotImplementedError(f'the bf16 kernels are written for hidden_dim = 128 (got {bb.width}): run a narrower model '
+                                  "on the exact-fp32 kernels (hip_dtype = 'fp32', hip_soft_dtype = None)")
+
+
 def _packed(bb):
+    _need_full_width(bb)
     key = bb._weights_key()
     if getattr(bb, '_stream_key', None) != key:
         bb._stream = pack_stream(bb)

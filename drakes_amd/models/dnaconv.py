@@ -5,8 +5,11 @@ Same constructor, parameter names and state_dict keys as the reference `CNNModel
 strict=True.  The torch modules below only HOLD parameters; `forward` runs the HIP kernels
 (drakes_amd/csrc) on channels-last activations [B, L, 128].
 
-Scope: the sampling configuration (clean_data=False, cls_free_guidance=False,
-classifier=False, hidden_dim=128); anything else raises.
+Scope: the sampling configuration (clean_data=False, cls_free_guidance=False, classifier=False).  hidden_dim is 128
+(the shipped checkpoints) or any smaller multiple of 8 (the reference takes it from args, dnaconv.py:46-63; cheap test
+models): a narrower model keeps its own parameter shapes and state_dict, and runs zero-padded into the kernels' 128
+lanes on the exact-fp32 kernels (LayerNorm takes its statistics over hidden_dim channels; padding lanes stay 0 in the
+forward pass and carry no gradient).  The bf16 fast path is for hidden_dim = 128 only and says so.
 """
 import copy
 
@@ -38,8 +41,10 @@ class CNNModel(nn.Module):
         if classifier or getattr(args, 'clean_data', False) or getattr(args, 'cls_free_guidance', False):
             raise NotImplementedError('drakes_amd.CNNModel covers the sampling configuration only '
                                       '(clean_data=False, cls_free_guidance=False, classifier=False)')
-        if args.hidden_dim != ops.C:
-            raise NotImplementedError(f'the gfx950 kernels are written for hidden_dim={ops.C}, got {args.hidden_dim}')
+        if not (8 <= args.hidden_dim <= ops.C and args.hidden_dim % 8 == 0):
+            raise NotImplementedError(f'hidden_dim must be a multiple of 8 up to {ops.C} (the kernels\' lane count), '
+                                      f'got {args.hidden_dim}')
+        self.width = args.hidden_dim
         if alphabet_size != ops.V:
             raise NotImplementedError(f'alphabet_size must be {ops.V} (A,C,G,T,mask)')
         if getattr(args, 'dropout', 0.0) != 0.0:
@@ -86,6 +91,47 @@ class CNNModel(nn.Module):
         self._streamT = None
         self._streamT_key = None
 
+    # ------------------------------------------------------------------ hidden_dim < 128: the 128-lane image
+    def wide(self, name, p):
+        """Parameter `name` of a hidden_dim = width model as the same parameter of the 128-channel model that computes
+        the same function on the first `width` channels: zero padding, except time_embedder.1.weight, whose input is
+        [sin(width/2), cos(width/2)] (dnaconv.py:21) and lands on the 128-model's sin lanes 0.. and cos lanes 64.. ."""
+        w, C = self.width, ops.C
+        if w == C:
+            return p
+        pad = lambda t, *dims: torch.nn.functional.pad(t, [x for d in reversed(range(t.ndim)) for x in (0, (C - t.shape[d]) if d in dims else 0)])
+        if name == 'time_embedder.0.W':
+            return torch.nn.functional.pad(p, (0, C // 2 - w // 2))
+        if name == 'time_embedder.1.weight':
+            out = p.new_zeros(C, C)
+            out[:w, :w // 2] = p[:, :w // 2]
+            out[:w, C // 2:C // 2 + w // 2] = p[:, w // 2:]
+            return out
+        if name == 'final_conv.2.weight':
+            return pad(p, 1)
+        if name == 'final_conv.2.bias':
+            return p
+        if name == 'linear.weight':
+            return pad(p, 0)
+        if p.ndim == 1:
+            return pad(p, 0)
+        return pad(p, 0, 1)
+
+    def narrow(self, name, g):
+        """Inverse of wide() on a gradient in the 128-channel layout."""
+        w, C = self.width, ops.C
+        if w == C or g is None:
+            return g
+        if name == 'time_embedder.1.weight':
+            return torch.cat([g[:w, :w // 2], g[:w, C // 2:C // 2 + w // 2]], dim=1)
+        if name == 'final_conv.2.weight':
+            return g[:, :w]
+        if name == 'final_conv.2.bias':
+            return g
+        if name == 'linear.weight' or g.ndim == 1:
+            return g[:w]
+        return g[:w, :w]
+
     def packed(self):
         """Kernel-layout copies of the weights; rebuilt when any parameter changed in place
         (optimizer step, load_state_dict) or moved."""
@@ -93,25 +139,26 @@ class CNNModel(nn.Module):
         if self._packed is None or key != self._packed_key:
             with torch.no_grad():
                 n = self.num_layers
+                P = {k: self.wide(k, v.detach()) for k, v in self.named_parameters()}
                 self._packed = {
-                    'stem_w': ops.pack_stem_weight(self.linear.weight),
-                    'stem_b': self.linear.bias.detach().contiguous(),
-                    'four_W': self.time_embedder[0].W.detach().contiguous(),
-                    'temb_w': self.time_embedder[1].weight.detach().contiguous(),
-                    'temb_b': self.time_embedder[1].bias.detach().contiguous(),
-                    'dense_w': torch.stack([self.time_layers[i].dense.weight.detach() for i in range(n)]).contiguous(),
-                    'dense_b': torch.stack([self.time_layers[i].dense.bias.detach() for i in range(n)]).contiguous(),
-                    'ln_g': [self.norms[i].weight.detach().contiguous() for i in range(n)],
-                    'ln_b': [self.norms[i].bias.detach().contiguous() for i in range(n)],
-                    'conv_w': [ops.pack_conv_weight_f32(self.convs[i].weight) for i in range(n)],
+                    'stem_w': ops.pack_stem_weight(P['linear.weight']),
+                    'stem_b': P['linear.bias'].contiguous(),
+                    'four_W': P['time_embedder.0.W'].contiguous(),
+                    'temb_w': P['time_embedder.1.weight'].contiguous(),
+                    'temb_b': P['time_embedder.1.bias'].contiguous(),
+                    'dense_w': torch.stack([P[f'time_layers.{i}.dense.weight'] for i in range(n)]).contiguous(),
+                    'dense_b': torch.stack([P[f'time_layers.{i}.dense.bias'] for i in range(n)]).contiguous(),
+                    'ln_g': [P[f'norms.{i}.weight'].contiguous() for i in range(n)],
+                    'ln_b': [P[f'norms.{i}.bias'].contiguous() for i in range(n)],
+                    'conv_w': [ops.pack_conv_weight_f32(P[f'convs.{i}.weight']) for i in range(n)],
                     # input-gradient weights: the same kernel run on weight.transpose(0,1).flip(2)
-                    'conv_wT': [ops.pack_conv_weight_f32(self.convs[i].weight.transpose(0, 1).flip(2)) for i in range(n)],
-                    'head0_wT': ops.pack_conv_weight_f32(self.final_conv[0].weight.transpose(0, 1)),
-                    'conv_b': [self.convs[i].bias.detach().contiguous() for i in range(n)],
-                    'head0_w': ops.pack_conv_weight_f32(self.final_conv[0].weight),
-                    'head0_b': self.final_conv[0].bias.detach().contiguous(),
-                    'head2_w': self.final_conv[2].weight.detach().reshape(self.alphabet_size, -1).contiguous(),
-                    'head2_b': self.final_conv[2].bias.detach().contiguous(),
+                    'conv_wT': [ops.pack_conv_weight_f32(P[f'convs.{i}.weight'].transpose(0, 1).flip(2)) for i in range(n)],
+                    'head0_wT': ops.pack_conv_weight_f32(P['final_conv.0.weight'].transpose(0, 1)),
+                    'conv_b': [P[f'convs.{i}.bias'].contiguous() for i in range(n)],
+                    'head0_w': ops.pack_conv_weight_f32(P['final_conv.0.weight']),
+                    'head0_b': P['final_conv.0.bias'].contiguous(),
+                    'head2_w': P['final_conv.2.weight'].reshape(self.alphabet_size, -1).contiguous(),
+                    'head2_b': P['final_conv.2.bias'].contiguous(),
                 }
             self._packed_key = key
         return self._packed
@@ -139,7 +186,7 @@ class CNNModel(nn.Module):
         feat = ops.stem_fwd(seq, pk['stem_w'], pk['stem_b'], out=buf('feat', B, L, ops.C))
         h = buf('h', B, L, ops.C)
         for i in range(self.num_layers):
-            ops.ln_fwd(feat, tbias[0, i], tb_stride, pk['ln_g'][i], pk['ln_b'][i], out=h)
+            ops.ln_fwd(feat, tbias[0, i], tb_stride, pk['ln_g'][i], pk['ln_b'][i], out=h, width=self.width)
             ops.conv_fwd_f32(h, pk['conv_w'][i], pk['conv_b'][i], feat, self.dilation(i), relu=True, out=feat)
         ops.conv_fwd_f32(feat, pk['head0_w'], pk['head0_b'], None, 0, relu=True, out=h)
         return ops.head_out_fwd(h, pk['head2_w'], pk['head2_b'], out=buf('logits', B, L, ops.V))

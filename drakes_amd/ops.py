@@ -153,14 +153,14 @@ def stem_fwd(x, w_t, bias, out=None):
     return out
 
 
-def ln_fwd(feat, tbias_layer, tb_stride, gamma, beta, out=None, mean=None, rstd=None):
+def ln_fwd(feat, tbias_layer, tb_stride, gamma, beta, out=None, mean=None, rstd=None, width=C):
     """tbias_layer: a view starting at this layer's 128 floats of batch row 0; tb_stride: floats
-    between batch rows (0 = shared)."""
+    between batch rows (0 = shared).  width: the model's hidden_dim when it is narrower than the 128 lanes."""
     B, L, _ = feat.shape
     out = out if out is not None else torch.empty_like(feat)
     tb = ctypes.c_void_p(tbias_layer.data_ptr()) if tbias_layer is not None else None
     _lib.call('drk_ln_fwd', _f(feat, 'feat'), tb, tb_stride, _f(gamma, 'gamma'), _f(beta, 'beta'), _f(out, 'h'),
-              _f(mean, 'mean'), _f(rstd, 'rstd'), B, L, _stream())
+              _f(mean, 'mean'), _f(rstd, 'rstd'), B, L, width, _stream())
     return out
 
 
@@ -211,7 +211,7 @@ def colsum128(x, n_seg, seg_rows, out):
 
 
 def ln_bwd(dh, feat, tbias_layer, tb_stride, gamma, mean, rstd, g_resid, dxin, dfeat, dgamma, dbeta, dtb_shared=None,
-           next_mask=None, dc_next=None, dbias_next=None):
+           next_mask=None, dc_next=None, dbias_next=None, width=C):
     """dxin may be None (not stored).  next_mask / dc_next / dbias_next: the fused hand-over to the layer below (bf16
     path): dc_next = bf16(dfeat * next_mask), dbias_next += its column sums."""
     B, L, _ = feat.shape
@@ -219,7 +219,7 @@ def ln_bwd(dh, feat, tbias_layer, tb_stride, gamma, mean, rstd, g_resid, dxin, d
     _lib.call('drk_ln_bwd', _f(dh, 'dh'), _f(feat, 'feat'), tb, tb_stride, _f(gamma, 'gamma'), _f(mean, 'mean'),
               _f(rstd, 'rstd'), _f(g_resid, 'g_resid'), _f(dxin, 'dxin'), _f(dfeat, 'dfeat'), _f(dgamma, 'dgamma'),
               _f(dbeta, 'dbeta'), _f(dtb_shared, 'dtbias_shared'), _dev_ptr(next_mask, torch.uint8, 'next_mask'),
-              _dev_ptr(dc_next, torch.bfloat16, 'dc_next'), _f(dbias_next, 'dbias_next'), B, L, _stream())
+              _dev_ptr(dc_next, torch.bfloat16, 'dc_next'), _f(dbias_next, 'dbias_next'), B, L, width, _stream())
 
 
 _WORKSPACE = {}

@@ -123,11 +123,13 @@ int drk_time_bias_fwd(const float* temb, int nb, const float* dense_w, const flo
  * feat [B][L][128]. */
 int drk_stem_fwd(const int64_t* x, const float* x_soft, const float* w_t, const float* bias, float* feat,
                  int B, int L, void* stream);
-/* h = LayerNorm_128(feat + tbias[:, None, :]) — dnaconv.py:90-95.  tbias row stride
+/* h = LayerNorm_width(feat + tbias[:, None, :]) — dnaconv.py:90-95.  tbias row stride
  * `tbias_bstride` floats between batch rows (0 = one row shared by the whole batch).
- * mean/rstd [B*L] are optional outputs for the backward pass. */
+ * mean/rstd [B*L] are optional outputs for the backward pass.
+ * width = args.hidden_dim (dnaconv.py:60), a multiple of 4 up to 128.  Rows are always 128 floats: a narrower model
+ * lives zero-padded in the first `width` lanes (gamma = beta = 0 beyond them), the statistics run over `width`. */
 int drk_ln_fwd(const float* feat, const float* tbias, long tbias_bstride, const float* gamma,
-               const float* beta, float* h, float* mean, float* rstd, int B, int L, void* stream);
+               const float* beta, float* h, float* mean, float* rstd, int B, int L, int width, void* stream);
 /* feat_out = relu(Conv1d(128->128,k=taps,dilation)(h) + bias) [+ resid] — dnaconv.py:96-98 and,
  * with taps=1 and resid=NULL, final_conv.0 + ReLU (:61-62,101).  Exact fp32 (f32-input MFMA).
  * w_pk [taps][32][128][4]: w_pk[t][g][co][q] = weight[co][4g+q][t].  bias may be NULL (= 0).
@@ -159,7 +161,7 @@ int drk_colsum128(const float* x, float* out, long n_seg, long seg_rows, void* s
 int drk_ln_bwd(const float* dh, const float* feat, const float* tbias, long tbias_bstride, const float* gamma,
                const float* mean, const float* rstd, const float* g_resid, float* dxin, float* dfeat,
                float* dgamma, float* dbeta, float* dtbias_shared, const unsigned char* next_mask, void* dc_next,
-               float* dbias_next, int B, int L, void* stream);
+               float* dbias_next, int B, int L, int width /* as in drk_ln_fwd */, void* stream);
 /* Conv1d weight gradient: dwt[t][ci][co] += sum_rows h[row + (t - taps/2)*dilation][ci] * dc[row][co].  dbias (optional, float32 [128], accumulated): column sums of dc,
  * the conv bias gradient, taken by the centre-tap workgroups on the way.  Deterministic split-K: every (row chunk, tap)
  * workgroup stores its 128x128 partial into `workspace` (device memory, 16-byte aligned, at least

@@ -115,3 +115,23 @@ def test_sample_prior_and_sigma_processing():
     assert torch.equal(m._process_sigma(s), torch.zeros(2))
     m.time_conditioning = True
     assert torch.equal(m._process_sigma(s), torch.tensor([0.3, 0.7]))
+
+
+def test_narrow_model_parameter_images():
+    """hidden_dim < 128 (reference: models/dnaconv.py:46-63 takes it from args): the reference's parameter shapes, and
+    a 128-lane image per parameter whose slices give the parameter back."""
+    import drakes_amd
+    m = drakes_amd.Diffusion(drakes_amd.default_config(hidden_dim=32))
+    bb = m.backbone
+    sd = m.state_dict()
+    assert sd['backbone.linear.weight'].shape == (32, 5, 9) and sd['backbone.final_conv.2.weight'].shape == (5, 32, 1)
+    assert sd['backbone.time_embedder.0.W'].shape == (16,) and sd['backbone.norms.19.weight'].shape == (32,)
+    full = dict(drakes_amd.Diffusion(drakes_amd.default_config()).backbone.named_parameters())
+    for name, p in bb.named_parameters():
+        w = bb.wide(name, p.detach())
+        assert w.shape == full[name].shape, name
+        assert float(w.double().abs().sum()) == float(p.detach().double().abs().sum()), name   # nothing but zeros added
+        if name != 'time_embedder.0.W':
+            assert torch.equal(bb.narrow(name, w), p.detach()), name
+    with pytest.raises(NotImplementedError):
+        drakes_amd.Diffusion(drakes_amd.default_config(hidden_dim=20))
