@@ -34,6 +34,7 @@ SIGNATURES = {
     'drk_stem_fwd': [_P, _P, _P, _P, _P, c_int, c_int, _P],
     'drk_ln_fwd': [_P, _P, c_long, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P],
     'drk_conv_fwd_f32': [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P],
+    'drk_conv_fwd_x3': [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P],
     'drk_mask_mul': [_P, _P, _P, c_long, _P],
     'drk_relu_bwd': [_P, _P, _P, c_long, _P],
     'drk_colsum128': [_P, _P, c_long, c_long, _P],

@@ -1,0 +1,247 @@
+// drk_conv_fwd_x3 — the residual layer's convolution (models/dnaconv.py:96-98) at fp32 GRADE on the bf16 matrix cores:
+// every fp32 operand is written as the sum of three bf16 numbers, x = x0 + x1 + x2 (x0 = bf16(x), x1 = bf16(x - x0),
+// x2 = bf16(x - x0 - x1): 3 x 8 significant bits cover fp32's 24), and a product w * h is taken as the six partial
+// products whose planes add up to at most 2 (w0h0, w0h1, w1h0, w0h2, w1h1, w2h0); the dropped ones are <= 2^-24 of the
+// product, one fp32 rounding.  bf16 x bf16 is exact in the fp32 accumulator, so the result differs from an fp32
+// convolution by summation order and those dropped terms only.  Six v_mfma_f32_16x16x32_bf16 (2.5 PFLOP/s dense) do the
+// work of one pass of the f32-input MFMA (157 TFLOP/s): 0.375 x its time at equal pipe occupancy.
+//
+// Same interface as drk_conv_fwd_f32: fp32 h in, fp32 out, bias + ReLU (+ mask) + residual fused.  The weights arrive
+// split (three bf16 fragment streams, fastpath._frag_tap order, packed once per weight update); the activations are
+// split by the thread that stages them, ONCE per element and tap, on their way from global memory into LDS, which holds
+// the three planes of a tap's 128 rows (splitting at the MFMA operand read instead — every element four times, once per
+// channel-tile wave — left the matrix pipe at 34 %: 44 VALU operations per 12 MFMAs saturate the vector issue port):
+// h stays fp32 in memory and the LayerNorm kernel stays the exact one.
+//
+// Workgroup = 512 threads = 8 waves (two per SIMD) on a tile of 128 rows x 128 output channels.  Wave (ct, kh) owns
+// output channels [32 ct, 32 ct + 32), ALL 128 rows, and input-channel half kh (k-steps 2 kh, 2 kh + 1): no weight
+// fragment is fetched twice inside a workgroup (the L1 does not merge duplicate requests, and three planes make the
+// weight stream 864 KB per layer).  After the tap loop the two halves of a tile meet through LDS and each wave finishes
+// 64 rows.  Each tap's 128 shifted rows are fetched as whole 512-byte rows, in flight in registers under the previous
+// tap's 192 MFMAs per wave, then split and parked ([row][plane][128 bf16], 784-byte rows; one buffer — two do not fit —
+// so two barriers per tap around the parking); rows whose shifted position leaves [0, L) are staged as zeros ('same'
+// padding and the sequence boundary in one test).
+// MFMA-bound: 6 x 295 kFLOP per row against 512 B x 9 taps of L2-resident re-reads + 864 KB of weights per 128 rows.
+#include "drk_common.h"
+#include "../../include/drakes_hip.h"
+
+typedef __bf16 bf16v8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16v2 __attribute__((ext_vector_type(2)));
+
+#define X3_ROWS 128
+#define X3_ROWB 784                      // 3 planes x 128 bf16 + 16 B pad
+#define X3_BUF (X3_ROWS * X3_ROWB)       // 100 352
+#define X3_PLANE_BYTES 32768             // one plane of one tap: [4 k-steps][4 ct][2 s][64 lanes][16 B]
+#define X3_TAP_BYTES (3 * X3_PLANE_BYTES)
+#define X3_KSTEP_BYTES 8192
+#define X3_SUB_BYTES 1024
+
+struct X3Args {
+  const float* h;           // fp32 [M][128]
+  const char* w3;           // [taps][3 planes][32 KB] bf16 fragments
+  const float* bias;        // [128] or NULL
+  const float* resid;       // fp32 [M][128] or NULL (may alias out)
+  float* out;               // fp32 [M][128]
+  unsigned char* mask;      // optional uint8 [M][128]
+  long M;
+  int L, taps, dil, first_tap, relu;
+};
+
+typedef __bf16 bf16v4 __attribute__((ext_vector_type(4)));
+
+// x (4 floats) -> three bf16 planes
+__device__ __forceinline__ void split3(const f32x4 x, bf16v4& p0, bf16v4& p1, bf16v4& p2) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const __bf16 a = (__bf16)x[j];
+    const float r1 = x[j] - (float)a;
+    const __bf16 b = (__bf16)r1;
+    const float r2 = r1 - (float)b;
+    p0[j] = a;
+    p1[j] = b;
+    p2[j] = (__bf16)r2;
+  }
+}
+
+__global__ void __launch_bounds__(512, 2) k_conv_x3(const X3Args a) {
+  __shared__ __attribute__((aligned(16))) char smem[X3_BUF];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int ct = __builtin_amdgcn_readfirstlane((tid >> 6) & 3);
+  const int kh = __builtin_amdgcn_readfirstlane(tid >> 8);
+  const int n = lane & 15, g = lane >> 4;
+  const int ch0 = 32 * ct + 4 * g;                       // this lane's 4 output channels of row tile s: ch0 + 16 s ..
+  const long r0 = (long)blockIdx.x * X3_ROWS;
+  const int L = a.L;
+  const unsigned p0 = (unsigned)(r0 % L);
+  const int center = a.taps / 2;
+  const int last_tap = a.taps - 1 - a.first_tap;
+
+  // staging role: rows srow + 16 i (i < 8), 16-byte chunk scol of the 512-byte row
+  const int srow = tid >> 5, scol = tid & 31;
+  int spos[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) spos[i] = (int)((p0 + srow + 16 * i) % (unsigned)L);
+  f32x4 stage[8];
+  auto fetch = [&](int off) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const long row = r0 + srow + 16 * i;
+      const int p = spos[i] + off;
+      stage[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (row < a.M && p >= 0 && p < L) stage[i] = *(const f32x4*)(a.h + (row + off) * DRK_C + 4 * scol);
+    }
+  };
+  auto park = [&]() {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      bf16v4 q0, q1, q2;
+      split3(stage[i], q0, q1, q2);
+      char* d = smem + (srow + 16 * i) * X3_ROWB + 8 * scol;
+      *(bf16v4*)(d) = q0;
+      *(bf16v4*)(d + 256) = q1;
+      *(bf16v4*)(d + 512) = q2;
+    }
+  };
+
+  f32x4 acc[8][2];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    acc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  // A fragments of one k-step: [plane][s]; the ring holds the k-step in use and the next one
+  const char* wlane = a.w3 + (2 * kh) * X3_KSTEP_BYTES + ct * (2 * X3_SUB_BYTES) + lane * 16;
+  bf16v8 wa[2][3][2];
+  auto load_w = [&](int slot, int tap, int ksl) {
+    const char* p = wlane + (long)tap * X3_TAP_BYTES + ksl * X3_KSTEP_BYTES;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+      wa[slot][pl][0] = *(const bf16v8*)(p + pl * X3_PLANE_BYTES);
+      wa[slot][pl][1] = *(const bf16v8*)(p + pl * X3_PLANE_BYTES + X3_SUB_BYTES);
+    }
+  };
+  load_w(0, a.first_tap, 0);
+  fetch((a.first_tap - center) * a.dil);
+  park();
+  __syncthreads();
+
+  // B operand: lane (n, g), k-step ks holds input channels 64 (g & 1) + 32 (g >> 1) + 8 ks + 0..7 of position n
+  const char* const base = smem + n * X3_ROWB + 2 * (64 * (g & 1) + 32 * (g >> 1) + 16 * kh);
+  for (int tap = a.first_tap; tap <= last_tap; ++tap) {
+    const bool more = tap < last_tap;
+    // requested in this order: loads return in order, and the second k-step's fragments are needed long before the
+    // next tap's rows
+    load_w(1, tap, 1);
+    if (more) fetch((tap + 1 - center) * a.dil);              // in flight under this tap's MFMAs
+#pragma unroll
+    for (int ksl = 0; ksl < 2; ++ksl) {
+      if (ksl == 1) load_w(0, more ? tap + 1 : tap, 0);       // the next tap's first k-step (unused after the last tap)
+      bf16v8 b0 = *(const bf16v8*)(base + 16 * ksl), b1 = *(const bf16v8*)(base + 16 * ksl + 256),
+             b2 = *(const bf16v8*)(base + 16 * ksl + 512);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const bf16v8 c0 = b0, c1 = b1, c2 = b2;
+        if (t + 1 < 8) {
+          const char* nb = base + (16 * (t + 1)) * X3_ROWB + 16 * ksl;
+          b0 = *(const bf16v8*)(nb);
+          b1 = *(const bf16v8*)(nb + 256);
+          b2 = *(const bf16v8*)(nb + 512);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          f32x4 c = acc[t][s];
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ksl][2][s], c0, c, 0, 0, 0);   // small terms first
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ksl][1][s], c1, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ksl][0][s], c2, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ksl][1][s], c0, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ksl][0][s], c1, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ksl][0][s], c0, c, 0, 0, 0);
+          acc[t][s] = c;
+        }
+      }
+    }
+    if (more) {
+      __syncthreads();       // every wave is past its reads of this tap's rows
+      park();
+      __syncthreads();
+    }
+  }
+
+  // ---- the two input-channel halves meet: kh 0 finishes rows 0..63, kh 1 rows 64..127 ---------------------------------
+  __syncthreads();           // every wave is past its reads of the activation buffers
+  f32x4 mine[4][2];
+  {
+    f32x4* const xw = (f32x4*)smem + (tid >> 6) * (8 * 64) + lane;            // [wave][8][64 lanes], 8 KB per wave
+    const f32x4* const xr = (const f32x4*)smem + ((tid >> 6) ^ 4) * (8 * 64) + lane;
+    if (kh == 0) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        xw[(2 * t) * 64] = acc[4 + t][0];
+        xw[(2 * t + 1) * 64] = acc[4 + t][1];
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        xw[(2 * t) * 64] = acc[t][0];
+        xw[(2 * t + 1) * 64] = acc[t][1];
+      }
+    }
+    __syncthreads();
+    if (kh == 0) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        mine[t][0] = acc[t][0] + xr[(2 * t) * 64];
+        mine[t][1] = acc[t][1] + xr[(2 * t + 1) * 64];
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        mine[t][0] = xr[(2 * t) * 64] + acc[4 + t][0];                         // (half 0) + (half 1) on both sides
+        mine[t][1] = xr[(2 * t + 1) * 64] + acc[4 + t][1];
+      }
+    }
+  }
+  // ---- epilogue: bias, ReLU (+ mask), residual -----------------------------------------------------------------------
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  const f32x4 cb0 = a.bias ? *(const f32x4*)(a.bias + ch0) : zero4, cb1 = a.bias ? *(const f32x4*)(a.bias + ch0 + 16) : zero4;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const long row = r0 + 64 * kh + 16 * t + n;
+    if (row >= a.M) continue;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      f32x4 r = mine[t][s] + (s ? cb1 : cb0);
+      if (a.relu) {
+        if (a.mask) {
+          const unsigned m = (r[0] > 0.f ? 1u : 0u) | (r[1] > 0.f ? 0x100u : 0u) | (r[2] > 0.f ? 0x10000u : 0u) |
+                             (r[3] > 0.f ? 0x1000000u : 0u);
+          *(unsigned*)(a.mask + row * DRK_C + ch0 + 16 * s) = m;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] = fmaxf(r[i], 0.f);
+      }
+      if (a.resid) r += *(const f32x4*)(a.resid + row * DRK_C + ch0 + 16 * s);
+      *(f32x4*)(a.out + row * DRK_C + ch0 + 16 * s) = r;
+    }
+  }
+}
+
+extern "C" int drk_conv_fwd_x3(const float* h, const void* w3, const float* bias, const float* resid, float* out,
+                               unsigned char* relu_mask, int B, int L, int taps, int dilation, int relu, void* stream) {
+  DRK_SHAPE_GUARD("drk_conv_fwd_x3");
+  if (!(h && w3 && out && taps >= 1 && (taps & 1) && dilation >= 0 && (const void*)h != (const void*)out))
+    return drk_set_error_msg(DRK_EINVAL, "drk_conv_fwd_x3: bad arguments (h and out must be distinct buffers)");
+  if (relu_mask && !relu) return drk_set_error_msg(DRK_EINVAL, "drk_conv_fwd_x3: a ReLU mask needs relu = 1");
+  X3Args a;
+  a.h = h; a.w3 = (const char*)w3; a.bias = bias; a.resid = resid; a.out = out; a.mask = relu_mask;
+  a.M = (long)B * L; a.L = L; a.taps = taps; a.dil = dilation; a.relu = relu ? 1 : 0;
+  if (a.M == 0) return DRK_OK;
+  const int center = taps / 2;
+  int reach = center;                      // taps whose shift is >= L read only padding: skipped
+  if (dilation > 0 && (L - 1) / dilation < reach) reach = (L - 1) / dilation;
+  a.first_tap = center - reach;
+  hipLaunchKernelGGL(k_conv_x3, dim3((unsigned)((a.M + X3_ROWS - 1) / X3_ROWS)), dim3(512), 0, (hipStream_t)stream, a);
+  DRK_CHECK_LAUNCH();
+  return DRK_OK;
+}

@@ -93,7 +93,7 @@ def sample_finetune_gradient(model, num_steps=None, eps=1e-5, eval_sp_size=None,
             with torch.no_grad():
                 if model.time_conditioning or shared is None:
                     shared = model._shared_time_bias(sigma_t)
-                logits = bb.forward_f32(x, shared, 0, model._work)
+                logits = (bb.forward_x3 if model.hip_dtype == 'bf16x3' else bb.forward_f32)(x, shared, 0, model._work)
                 x_next = ops.reverse_step_hard(logits, x, mc_t, mc_s, seed, i, sample_offset, u)
                 last_x = F.one_hot(x, num_classes=model.vocab_size).to(torch.float32)
                 copy_flag = (x != model.mask_index).to(x.dtype).unsqueeze(-1)

@@ -90,6 +90,8 @@ class CNNModel(nn.Module):
         self._stream_key = None
         self._streamT = None
         self._streamT_key = None
+        self._x3 = None
+        self._x3_key = None
 
     # ------------------------------------------------------------------ hidden_dim < 128: the 128-lane image
     def wide(self, name, p):
@@ -170,7 +172,23 @@ class CNNModel(nn.Module):
         temb = ops.time_embed_fwd(t.contiguous(), pk['four_W'], pk['temb_w'], pk['temb_b'])
         return ops.time_bias_fwd(temb, pk['dense_w'], pk['dense_b'])
 
-    def forward_f32(self, seq, tbias, tb_stride, work=None):
+    def packed_x3(self):
+        """The conv weights as three bf16 planes in fragment order (drk_conv_fwd_x3), cached like packed()."""
+        key = self._weights_key()
+        if getattr(self, '_x3', None) is None or key != self._x3_key:
+            with torch.no_grad():
+                P = {k: self.wide(k, v.detach()) for k, v in self.named_parameters()}
+                self._x3 = {'conv_w3': [ops.pack_conv_weight_x3(P[f'convs.{i}.weight']) for i in range(self.num_layers)],
+                            'head0_w3': ops.pack_conv_weight_x3(P['final_conv.0.weight'])}
+            self._x3_key = key
+        return self._x3
+
+    def forward_x3(self, seq, tbias, tb_stride, work=None):
+        """forward_f32 with the convolutions at fp32 grade on the bf16 matrix cores (three bf16 planes per operand,
+        drk_conv_fwd_x3): logits within ~1e-5 of forward_f32's, about 3x its speed at large batches."""
+        return self.forward_f32(seq, tbias, tb_stride, work, x3=True)
+
+    def forward_f32(self, seq, tbias, tb_stride, work=None, x3=False):
         """Exact-fp32 kernels.  seq int64 [B,L] or float32 [B,L,5]; tbias [nb,n_layers,128]
         with `tb_stride` floats between batch rows (0 when one row serves the batch)."""
         pk = self.packed()
@@ -187,8 +205,14 @@ class CNNModel(nn.Module):
         h = buf('h', B, L, ops.C)
         for i in range(self.num_layers):
             ops.ln_fwd(feat, tbias[0, i], tb_stride, pk['ln_g'][i], pk['ln_b'][i], out=h, width=self.width)
-            ops.conv_fwd_f32(h, pk['conv_w'][i], pk['conv_b'][i], feat, self.dilation(i), relu=True, out=feat)
-        ops.conv_fwd_f32(feat, pk['head0_w'], pk['head0_b'], None, 0, relu=True, out=h)
+            if x3:
+                ops.conv_fwd_x3(h, self.packed_x3()['conv_w3'][i], pk['conv_b'][i], feat, self.dilation(i), relu=True, out=feat)
+            else:
+                ops.conv_fwd_f32(h, pk['conv_w'][i], pk['conv_b'][i], feat, self.dilation(i), relu=True, out=feat)
+        if x3:
+            ops.conv_fwd_x3(feat, self.packed_x3()['head0_w3'], pk['head0_b'], None, 0, relu=True, out=h)
+        else:
+            ops.conv_fwd_f32(feat, pk['head0_w'], pk['head0_b'], None, 0, relu=True, out=h)
         return ops.head_out_fwd(h, pk['head2_w'], pk['head2_b'], out=buf('logits', B, L, ops.V))
 
     def forward(self, seq, t, cls=None, return_embedding=False):

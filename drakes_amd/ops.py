@@ -177,6 +177,37 @@ def conv_fwd_f32(h, w_pk, bias, resid, dilation, relu=True, out=None, relu_mask=
     return out
 
 
+def split3_bf16(w):
+    """fp32 -> three bf16 planes whose sum is w to 2^-24 relative (drk_conv_x3.hip splits activations the same way)."""
+    w = w.detach().float()
+    p0 = w.to(torch.bfloat16)
+    r1 = w - p0.float()
+    p1 = r1.to(torch.bfloat16)
+    p2 = (r1 - p1.float()).to(torch.bfloat16)
+    return p0, p1, p2
+
+
+def pack_conv_weight_x3(w):
+    """[co][ci][taps] fp32 -> bf16 [taps][3 planes][4][4][2][64][8] (drk_conv_fwd_x3's w3)."""
+    from .fastpath import _frag_tap
+    planes = split3_bf16(w)
+    return torch.stack([torch.stack([_frag_tap(p[:, :, t].float()) for p in planes]) for t in range(w.shape[2])]).contiguous()
+
+
+def conv_fwd_x3(h, w3, bias, resid, dilation, relu=True, out=None, relu_mask=None):
+    """drk_conv_fwd_f32's operation at fp32 grade on the bf16 matrix cores (three bf16 planes per operand)."""
+    B, L, _ = h.shape
+    taps = w3.shape[0]
+    out = out if out is not None else torch.empty_like(h)
+    args = (_f(h, 'h'), _dev_ptr(w3, torch.bfloat16, 'w3'), _f(bias, 'bias'), _f(resid, 'resid'), _f(out, 'out'),
+            _dev_ptr(relu_mask, torch.uint8, 'relu_mask'), B, L, taps, dilation, 1 if relu else 0, _stream())
+    if taps == 9:
+        PROFILE.bracket('k_conv_x3', 2.0 * B * L * C * C * taps, lambda: _lib.call('drk_conv_fwd_x3', *args))
+    else:
+        _lib.call('drk_conv_fwd_x3', *args)
+    return out
+
+
 def head_out_fwd(y, w, bias, out=None):
     B, L, _ = y.shape
     out = out if out is not None else torch.empty(B, L, V, dtype=torch.float32, device=y.device)

@@ -138,6 +138,15 @@ int drk_ln_fwd(const float* feat, const float* tbias, long tbias_bstride, const 
  * weight.transpose(0,1).flip(2), bias = NULL, relu = 0. */
 int drk_conv_fwd_f32(const float* h, const float* w_pk, const float* bias, const float* resid, float* out,
                      unsigned char* relu_mask, int B, int L, int taps, int dilation, int relu, void* stream);
+/* The same operation as drk_conv_fwd_f32 (dnaconv.py:96-98; taps = 1: final_conv.0, :61-62,101) at fp32 GRADE on the
+ * bf16 matrix cores: weights and activations are each taken as three bf16 planes (x = x0 + x1 + x2 covers fp32's 24
+ * bits) and a product as the six partial products of plane sum <= 2, accumulated in fp32 — the result differs from the
+ * exact-fp32 kernel's by summation order and by dropped terms of <= 2^-24 per product.  h stays fp32 (split in
+ * registers); w3 = the split weights, bf16 [taps][3 planes][4 k-steps][4][2][64][8] in the fragment order of
+ * drk_layer_bf16's stream (drakes_amd/ops.py::pack_conv_weight_x3).  h and out must be distinct; out may alias resid.
+ * Also the input gradient, as for drk_conv_fwd_f32. */
+int drk_conv_fwd_x3(const float* h, const void* w3, const float* bias, const float* resid, float* out,
+                    unsigned char* relu_mask, int B, int L, int taps, int dilation, int relu, void* stream);
 /* logits = Conv1d(128->5,k=1)(y) — dnaconv.py:63,101-102.  w [5][128]; logits [B][L][5]. */
 int drk_head_out_fwd(const float* y, const float* w, const float* bias, float* logits, int B, int L,
                      void* stream);
