@@ -45,6 +45,11 @@ class _BackboneFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, bb, seq, sigma, *params):
         pk = bb.packed()
+        # train_dtype 'bf16x3': the convolutions (forward and input gradient) at fp32 grade on the bf16 matrix cores
+        # (drk_conv_fwd_x3); weight gradients and everything else stay on the exact-fp32 kernels
+        x3 = bb.packed_x3() if getattr(bb, 'train_dtype', 'fp32') == 'bf16x3' else None
+        conv = (lambda hh, i, *a, **k: ops.conv_fwd_x3(hh, x3['conv_w3'][i], *a, **k)) if x3 else \
+               (lambda hh, i, *a, **k: ops.conv_fwd_f32(hh, pk['conv_w'][i], *a, **k))
         seq = seq.contiguous()
         B, L = seq.shape[0], seq.shape[1]
         n = bb.num_layers
@@ -62,11 +67,14 @@ class _BackboneFn(torch.autograd.Function):
             rstd = torch.empty_like(mean)
             ops.ln_fwd(feats[i], tbias[0, i], tb_stride, pk['ln_g'][i], pk['ln_b'][i], out=h, mean=mean, rstd=rstd, width=bb.width)
             mask = torch.empty(B, L, C, dtype=torch.uint8, device=seq.device)
-            feats.append(ops.conv_fwd_f32(h, pk['conv_w'][i], pk['conv_b'][i], feats[i], bb.dilation(i), relu=True,
-                                          relu_mask=mask))
+            feats.append(conv(h, i, pk['conv_b'][i], feats[i], bb.dilation(i), relu=True, relu_mask=mask))
             means.append(mean), rstds.append(rstd), masks.append(mask)
-        y = ops.conv_fwd_f32(feats[n], pk['head0_w'], pk['head0_b'], None, 0, relu=True)
+        if x3:
+            y = ops.conv_fwd_x3(feats[n], x3['head0_w3'], pk['head0_b'], None, 0, relu=True)
+        else:
+            y = ops.conv_fwd_f32(feats[n], pk['head0_w'], pk['head0_b'], None, 0, relu=True)
         logits = ops.head_out_fwd(y, pk['head2_w'], pk['head2_b'])
+        ctx.x3 = x3
         ctx.bb, ctx.pk, ctx.seq, ctx.sigma, ctx.temb, ctx.tbias, ctx.tb_stride = bb, pk, seq, sigma, temb, tbias, tb_stride
         ctx.feats, ctx.means, ctx.rstds, ctx.masks, ctx.y = feats, means, rstds, masks, y
         ctx.names = [k for k, _ in bb.named_parameters()]
@@ -92,7 +100,11 @@ class _BackboneFn(torch.autograd.Function):
         db0 = zeros(1, C)
         if want_w:
             ops.conv_wgrad_f32(feats[n], dpre, dw0, 0, db0[0])
-        gr = ops.conv_fwd_f32(dpre, pk['head0_wT'], None, None, 0, relu=False)
+        x3 = ctx.x3
+        if x3:
+            gr = ops.conv_fwd_x3(dpre, x3['head0_w3T'], None, None, 0, relu=False)
+        else:
+            gr = ops.conv_fwd_f32(dpre, pk['head0_wT'], None, None, 0, relu=False)
         g['final_conv.2.weight'], g['final_conv.2.bias'] = dw2.unsqueeze(-1), db2
         g['final_conv.0.weight'], g['final_conv.0.bias'] = dw0.permute(2, 1, 0), db0[0]
         # layers
@@ -109,7 +121,10 @@ class _BackboneFn(torch.autograd.Function):
                 dwt, dbias = zeros(9, C, C), zeros(C)
                 ops.conv_wgrad_f32(h, dc, dwt, d, dbias)          # the bias gradient rides on the centre tap
                 g[f'convs.{i}.weight'], g[f'convs.{i}.bias'] = dwt.permute(2, 1, 0), dbias
-            ops.conv_fwd_f32(dc, pk['conv_wT'][i], None, None, d, relu=False, out=dh)
+            if x3:
+                ops.conv_fwd_x3(dc, x3['conv_w3T'][i], None, None, d, relu=False, out=dh)
+            else:
+                ops.conv_fwd_f32(dc, pk['conv_wT'][i], None, None, d, relu=False, out=dh)
             dgam, dbet = zeros(C), zeros(C)
             gnew = torch.empty_like(y)
             shared_tb = want_w and not ctx.tb_stride          # one time-bias row for the batch: its gradient is fused in
@@ -267,9 +282,12 @@ class _BackboneBf16Fn(torch.autograd.Function):
         return (None, dseq if ctx.needs_input_grad[1] else None, None, *grads)
 
 
-def backbone_with_grad(bb, seq, sigma, bf16=False):
-    """bf16: the bf16-MFMA layer kernels (gradients within the bf16 bar); default: the exact-fp32 kernels."""
-    fn = _BackboneBf16Fn if bf16 else _BackboneFn
+def backbone_with_grad(bb, seq, sigma, dtype='fp32'):
+    """dtype 'bf16': the bf16-MFMA layer kernels (gradients within the bf16 bar); 'fp32': the exact-fp32 kernels;
+    'bf16x3': those with the convolutions at fp32 grade on the bf16 matrix cores (read from bb.train_dtype)."""
+    if dtype is True:
+        dtype = 'bf16'
+    fn = _BackboneBf16Fn if dtype == 'bf16' else _BackboneFn
     return fn.apply(bb, seq, sigma, *bb.parameters())
 
 

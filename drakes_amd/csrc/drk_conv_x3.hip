@@ -22,19 +22,28 @@
 // so two barriers per tap around the parking); rows whose shifted position leaves [0, L) are staged as zeros ('same'
 // padding and the sequence boundary in one test).
 // MFMA-bound: 6 x 295 kFLOP per row against 512 B x 9 taps of L2-resident re-reads + 864 KB of weights per 128 rows.
+#include <atomic>
 #include "drk_common.h"
 #include "../../include/drakes_hip.h"
 
 typedef __bf16 bf16v8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16v2 __attribute__((ext_vector_type(2)));
 
-#define X3_ROWS 128
+#define X3_NT 6                          // 16-row tiles per workgroup tile
+#define X3_ROWS (16 * X3_NT)             // 96: two buffers of 96 rows x three planes fit the LDS, two of 128 do not
 #define X3_ROWB 784                      // 3 planes x 128 bf16 + 16 B pad
-#define X3_BUF (X3_ROWS * X3_ROWB)       // 100 352
+#define X3_BUF (X3_ROWS * X3_ROWB)       // 75 264
 #define X3_PLANE_BYTES 32768             // one plane of one tap: [4 k-steps][4 ct][2 s][64 lanes][16 B]
 #define X3_TAP_BYTES (3 * X3_PLANE_BYTES)
 #define X3_KSTEP_BYTES 8192
 #define X3_SUB_BYTES 1024
+
+// -DX3_STAMPS (tools/x3_stamps.py, never shipped): thread 0 stamps the phases of each workgroup's SECOND tile into `mask`
+#ifdef X3_STAMPS
+#define X3_STAMP(i) do { if (threadIdx.x == 0 && tile == t_begin + 1) ((unsigned long long*)a.mask)[blockIdx.x * 16 + (i)] = wall_clock64(); } while (0)
+#else
+#define X3_STAMP(i) do { } while (0)
+#endif
 
 struct X3Args {
   const float* h;           // fp32 [M][128]
@@ -63,52 +72,61 @@ __device__ __forceinline__ void split3(const f32x4 x, bf16v4& p0, bf16v4& p1, bf
   }
 }
 
-__global__ void __launch_bounds__(512, 2) k_conv_x3(const X3Args a) {
-  __shared__ __attribute__((aligned(16))) char smem[X3_BUF];
+__global__ void __launch_bounds__(512, 2) k_conv_x3(const X3Args a, const int tiles_per_wg, const int ntiles) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * X3_BUF];
+  // one workgroup per CU (147 KB of LDS) walks a contiguous run of tiles; (tile, tap) pairs form ONE stream of staged row
+  // sets: the rows of the next pair are fetched at the start of this pair's MFMAs and split + parked into the other
+  // buffer half-way through them, so the vector work of the split runs beside the matrix pipe and there is one barrier
+  // per tap
+  const int t_begin = blockIdx.x * tiles_per_wg;
+  const int t_end = t_begin + tiles_per_wg < ntiles ? t_begin + tiles_per_wg : ntiles;
+  if (t_begin >= t_end) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const int ct = __builtin_amdgcn_readfirstlane((tid >> 6) & 3);
   const int kh = __builtin_amdgcn_readfirstlane(tid >> 8);
   const int n = lane & 15, g = lane >> 4;
   const int ch0 = 32 * ct + 4 * g;                       // this lane's 4 output channels of row tile s: ch0 + 16 s ..
-  const long r0 = (long)blockIdx.x * X3_ROWS;
   const int L = a.L;
-  const unsigned p0 = (unsigned)(r0 % L);
   const int center = a.taps / 2;
   const int last_tap = a.taps - 1 - a.first_tap;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
-  // staging role: rows srow + 16 i (i < 8), 16-byte chunk scol of the 512-byte row
+  // staging role: rows srow + 16 i (i < X3_NT), 16-byte chunk scol of the 512-byte row
   const int srow = tid >> 5, scol = tid & 31;
-  int spos[8];
+  f32x4 stage[X3_NT];
+  auto positions = [&](long r0, int (&sp)[X3_NT]) {
+    const unsigned p0 = (unsigned)(r0 % L);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) spos[i] = (int)((p0 + srow + 16 * i) % (unsigned)L);
-  f32x4 stage[8];
-  auto fetch = [&](int off) {
+    for (int i = 0; i < X3_NT; ++i) sp[i] = (int)((p0 + srow + 16 * i) % (unsigned)L);
+  };
+  // Loads are unconditional on clamped addresses and the rows that must read as zero are blanked when they are parked:
+  // a zero-fill + predicated load here makes the compiler wait for EVERY load in flight (the weight fragments requested
+  // just before) ahead of the fill, once per tap.
+  unsigned live = 0;
+  auto fetch = [&](long r0, const int (&sp)[X3_NT], int off) {
+    live = 0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < X3_NT; ++i) {
       const long row = r0 + srow + 16 * i;
-      const int p = spos[i] + off;
-      stage[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (row < a.M && p >= 0 && p < L) stage[i] = *(const f32x4*)(a.h + (row + off) * DRK_C + 4 * scol);
+      const int p = sp[i] + off;
+      const bool ok = row < a.M && p >= 0 && p < L;
+      live |= ok ? (1u << i) : 0u;
+      long src = row + off;
+      src = src < 0 ? 0 : src >= a.M ? a.M - 1 : src;
+      stage[i] = *(const f32x4*)(a.h + src * DRK_C + 4 * scol);
     }
   };
-  auto park = [&]() {
+  auto park = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < X3_NT; ++i) {
       bf16v4 q0, q1, q2;
-      split3(stage[i], q0, q1, q2);
-      char* d = smem + (srow + 16 * i) * X3_ROWB + 8 * scol;
+      split3((live >> i) & 1 ? stage[i] : zero4, q0, q1, q2);
+      char* d = smem + buf * X3_BUF + (srow + 16 * i) * X3_ROWB + 8 * scol;
       *(bf16v4*)(d) = q0;
       *(bf16v4*)(d + 256) = q1;
       *(bf16v4*)(d + 512) = q2;
     }
   };
-
-  f32x4 acc[8][2];
-#pragma unroll
-  for (int t = 0; t < 8; ++t) {
-    acc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-    acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
 
   // A fragments of one k-step: [plane][s]; the ring holds the k-step in use and the next one
   const char* wlane = a.w3 + (2 * kh) * X3_KSTEP_BYTES + ct * (2 * X3_SUB_BYTES) + lane * 16;
@@ -121,109 +139,149 @@ __global__ void __launch_bounds__(512, 2) k_conv_x3(const X3Args a) {
       wa[slot][pl][1] = *(const bf16v8*)(p + pl * X3_PLANE_BYTES + X3_SUB_BYTES);
     }
   };
+  int spos[X3_NT];
+  positions((long)t_begin * X3_ROWS, spos);
   load_w(0, a.first_tap, 0);
-  fetch((a.first_tap - center) * a.dil);
-  park();
+  fetch((long)t_begin * X3_ROWS, spos, (a.first_tap - center) * a.dil);
+  park(0);
   __syncthreads();
 
   // B operand: lane (n, g), k-step ks holds input channels 64 (g & 1) + 32 (g >> 1) + 8 ks + 0..7 of position n
-  const char* const base = smem + n * X3_ROWB + 2 * (64 * (g & 1) + 32 * (g >> 1) + 16 * kh);
-  for (int tap = a.first_tap; tap <= last_tap; ++tap) {
-    const bool more = tap < last_tap;
-    // requested in this order: loads return in order, and the second k-step's fragments are needed long before the
-    // next tap's rows
-    load_w(1, tap, 1);
-    if (more) fetch((tap + 1 - center) * a.dil);              // in flight under this tap's MFMAs
+  const int boff = n * X3_ROWB + 2 * (64 * (g & 1) + 32 * (g >> 1) + 16 * kh);
+  int buf = 0;
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    const long r0 = (long)tile * X3_ROWS;
+    const bool next_tile = tile + 1 < t_end;
+    f32x4 acc[X3_NT][2];
 #pragma unroll
-    for (int ksl = 0; ksl < 2; ++ksl) {
-      if (ksl == 1) load_w(0, more ? tap + 1 : tap, 0);       // the next tap's first k-step (unused after the last tap)
-      bf16v8 b0 = *(const bf16v8*)(base + 16 * ksl), b1 = *(const bf16v8*)(base + 16 * ksl + 256),
-             b2 = *(const bf16v8*)(base + 16 * ksl + 512);
+    for (int t = 0; t < X3_NT; ++t) {
+      acc[t][0] = zero4;
+      acc[t][1] = zero4;
+    }
+    X3_STAMP(0);
+    for (int tap = a.first_tap; tap <= last_tap; ++tap) {
+      const bool more = tap < last_tap;
+      const bool staged = more || next_tile;
+      // requested in this order: loads return in order, and the second k-step's fragments are needed long before the
+      // next rows
+      load_w(1, tap, 1);
+      if (more) {
+        fetch(r0, spos, (tap + 1 - center) * a.dil);
+      } else if (next_tile) {
+        positions(r0 + X3_ROWS, spos);
+        fetch(r0 + X3_ROWS, spos, (a.first_tap - center) * a.dil);
+      }
+      const char* const base = smem + buf * X3_BUF + boff;
 #pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        const bf16v8 c0 = b0, c1 = b1, c2 = b2;
-        if (t + 1 < 8) {
-          const char* nb = base + (16 * (t + 1)) * X3_ROWB + 16 * ksl;
-          b0 = *(const bf16v8*)(nb);
-          b1 = *(const bf16v8*)(nb + 256);
-          b2 = *(const bf16v8*)(nb + 512);
+      for (int ksl = 0; ksl < 2; ++ksl) {
+        if (ksl == 1) {
+          load_w(0, more ? tap + 1 : a.first_tap, 0);    // the next tap's (or the next tile's) first k-step
+          if (staged) park(buf ^ 1);                     // the other buffer: its readers finished before the last barrier
         }
+        bf16v8 b0 = *(const bf16v8*)(base + 16 * ksl), b1 = *(const bf16v8*)(base + 16 * ksl + 256),
+               b2 = *(const bf16v8*)(base + 16 * ksl + 512);
+        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          f32x4 c = acc[t][s];
-          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ksl][2][s], c0, c, 0, 0, 0);   // small terms first
-          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ksl][1][s], c1, c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ksl][0][s], c2, c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ksl][1][s], c0, c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ksl][0][s], c1, c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ksl][0][s], c0, c, 0, 0, 0);
-          acc[t][s] = c;
+        for (int t = 0; t < X3_NT; ++t) {
+          const bf16v8 c0 = b0, c1 = b1, c2 = b2;
+          if (t + 1 < X3_NT) {
+            const char* nb = base + (16 * (t + 1)) * X3_ROWB + 16 * ksl;
+            b0 = *(const bf16v8*)(nb);
+            b1 = *(const bf16v8*)(nb + 256);
+            b2 = *(const bf16v8*)(nb + 512);
+          }
+          // two accumulation chains side by side (a dependent v_mfma waits ~40 cycles for its predecessor, an
+          // independent one issues after 16); small terms first
+          f32x4 e0 = acc[t][0], e1 = acc[t][1];
+          e0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ksl][2][0], c0, e0, 0, 0, 0);
+          e1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ksl][2][1], c0, e1, 0, 0, 0);
+          e0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ksl][1][0], c1, e0, 0, 0, 0);
+          e1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ksl][1][1], c1, e1, 0, 0, 0);
+          e0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ksl][0][0], c2, e0, 0, 0, 0);
+          e1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ksl][0][1], c2, e1, 0, 0, 0);
+          e0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ksl][1][0], c0, e0, 0, 0, 0);
+          e1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ksl][1][1], c0, e1, 0, 0, 0);
+          e0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ksl][0][0], c1, e0, 0, 0, 0);
+          e1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ksl][0][1], c1, e1, 0, 0, 0);
+          e0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ksl][0][0], c0, e0, 0, 0, 0);
+          e1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ksl][0][1], c0, e1, 0, 0, 0);
+          acc[t][0] = e0;
+          acc[t][1] = e1;
+          // the next row tile's three fragments are read BEFORE this tile's 12 MFMAs issue (left alone, the compiler
+          // sinks the reads to just before their first use and every tile waits out an LDS round trip)
+          if (t + 1 < X3_NT) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
         }
       }
+      X3_STAMP(1 + 2 * (tap - a.first_tap > 3 ? 4 : tap - a.first_tap));
+      __syncthreads();         // this tap's rows have been read by every wave, the next ones are parked
+      X3_STAMP(2 + 2 * (tap - a.first_tap > 3 ? 4 : tap - a.first_tap));
+      if (staged) buf ^= 1;
     }
-    if (more) {
-      __syncthreads();       // every wave is past its reads of this tap's rows
-      park();
-      __syncthreads();
-    }
-  }
 
-  // ---- the two input-channel halves meet: kh 0 finishes rows 0..63, kh 1 rows 64..127 ---------------------------------
-  __syncthreads();           // every wave is past its reads of the activation buffers
-  f32x4 mine[4][2];
-  {
-    f32x4* const xw = (f32x4*)smem + (tid >> 6) * (8 * 64) + lane;            // [wave][8][64 lanes], 8 KB per wave
-    const f32x4* const xr = (const f32x4*)smem + ((tid >> 6) ^ 4) * (8 * 64) + lane;
-    if (kh == 0) {
+    // ---- the two input-channel halves meet through the buffer that holds no staged rows: kh 0 finishes the first
+    // X3_NT/2 row tiles, kh 1 the others -----------------------------------------------------------------------------------
+    constexpr int HT = X3_NT / 2;
+    f32x4 mine[HT][2];
+    {
+      char* const xbuf = smem + (next_tile ? (buf ^ 1) : buf) * X3_BUF;
+      f32x4* const xw = (f32x4*)xbuf + (tid >> 6) * (2 * HT * 64) + lane;     // [wave][2 HT][64 lanes]
+      const f32x4* const xr = (const f32x4*)xbuf + ((tid >> 6) ^ 4) * (2 * HT * 64) + lane;
+      if (kh == 0) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        xw[(2 * t) * 64] = acc[4 + t][0];
-        xw[(2 * t + 1) * 64] = acc[4 + t][1];
-      }
-    } else {
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        xw[(2 * t) * 64] = acc[t][0];
-        xw[(2 * t + 1) * 64] = acc[t][1];
-      }
-    }
-    __syncthreads();
-    if (kh == 0) {
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        mine[t][0] = acc[t][0] + xr[(2 * t) * 64];
-        mine[t][1] = acc[t][1] + xr[(2 * t + 1) * 64];
-      }
-    } else {
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        mine[t][0] = xr[(2 * t) * 64] + acc[4 + t][0];                         // (half 0) + (half 1) on both sides
-        mine[t][1] = xr[(2 * t + 1) * 64] + acc[4 + t][1];
-      }
-    }
-  }
-  // ---- epilogue: bias, ReLU (+ mask), residual -----------------------------------------------------------------------
-  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-  const f32x4 cb0 = a.bias ? *(const f32x4*)(a.bias + ch0) : zero4, cb1 = a.bias ? *(const f32x4*)(a.bias + ch0 + 16) : zero4;
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const long row = r0 + 64 * kh + 16 * t + n;
-    if (row >= a.M) continue;
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      f32x4 r = mine[t][s] + (s ? cb1 : cb0);
-      if (a.relu) {
-        if (a.mask) {
-          const unsigned m = (r[0] > 0.f ? 1u : 0u) | (r[1] > 0.f ? 0x100u : 0u) | (r[2] > 0.f ? 0x10000u : 0u) |
-                             (r[3] > 0.f ? 0x1000000u : 0u);
-          *(unsigned*)(a.mask + row * DRK_C + ch0 + 16 * s) = m;
+        for (int t = 0; t < HT; ++t) {
+          xw[(2 * t) * 64] = acc[HT + t][0];
+          xw[(2 * t + 1) * 64] = acc[HT + t][1];
         }
+      } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) r[i] = fmaxf(r[i], 0.f);
+        for (int t = 0; t < HT; ++t) {
+          xw[(2 * t) * 64] = acc[t][0];
+          xw[(2 * t + 1) * 64] = acc[t][1];
+        }
       }
-      if (a.resid) r += *(const f32x4*)(a.resid + row * DRK_C + ch0 + 16 * s);
-      *(f32x4*)(a.out + row * DRK_C + ch0 + 16 * s) = r;
+      __syncthreads();
+      if (kh == 0) {
+#pragma unroll
+        for (int t = 0; t < HT; ++t) {
+          mine[t][0] = acc[t][0] + xr[(2 * t) * 64];
+          mine[t][1] = acc[t][1] + xr[(2 * t + 1) * 64];
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < HT; ++t) {
+          mine[t][0] = xr[(2 * t) * 64] + acc[HT + t][0];                     // (half 0) + (half 1) on both sides
+          mine[t][1] = xr[(2 * t + 1) * 64] + acc[HT + t][1];
+        }
+      }
     }
+    X3_STAMP(11);
+    // ---- epilogue: bias, ReLU (+ mask), residual ---------------------------------------------------------------------
+    const f32x4 cb0 = a.bias ? *(const f32x4*)(a.bias + ch0) : zero4, cb1 = a.bias ? *(const f32x4*)(a.bias + ch0 + 16) : zero4;
+#pragma unroll
+    for (int t = 0; t < HT; ++t) {
+      const long row = r0 + 16 * HT * kh + 16 * t + n;
+      if (row >= a.M) continue;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        f32x4 r = mine[t][s] + (s ? cb1 : cb0);
+        if (a.relu) {
+#ifndef X3_STAMPS
+          if (a.mask) {
+            const unsigned m = (r[0] > 0.f ? 1u : 0u) | (r[1] > 0.f ? 0x100u : 0u) | (r[2] > 0.f ? 0x10000u : 0u) |
+                               (r[3] > 0.f ? 0x1000000u : 0u);
+            *(unsigned*)(a.mask + row * DRK_C + ch0 + 16 * s) = m;
+          }
+#endif
+#pragma unroll
+          for (int i = 0; i < 4; ++i) r[i] = fmaxf(r[i], 0.f);
+        }
+        if (a.resid) r += *(const f32x4*)(a.resid + row * DRK_C + ch0 + 16 * s);
+        *(f32x4*)(a.out + row * DRK_C + ch0 + 16 * s) = r;
+      }
+    }
+    X3_STAMP(12);
+    if (next_tile) __syncthreads();   // the exchange buffer is free again before the next tile's second tap parks into it
   }
 }
 
@@ -241,7 +299,22 @@ extern "C" int drk_conv_fwd_x3(const float* h, const void* w3, const float* bias
   int reach = center;                      // taps whose shift is >= L read only padding: skipped
   if (dilation > 0 && (L - 1) / dilation < reach) reach = (L - 1) / dilation;
   a.first_tap = center - reach;
-  hipLaunchKernelGGL(k_conv_x3, dim3((unsigned)((a.M + X3_ROWS - 1) / X3_ROWS)), dim3(512), 0, (hipStream_t)stream, a);
+  const long ntiles = (a.M + X3_ROWS - 1) / X3_ROWS;
+  if (ntiles >= (1L << 30)) return drk_set_error_msg(DRK_EINVAL, "drk_conv_fwd_x3: too many rows");
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    static std::atomic<int> cu_count[DRK_MAX_DEVICES];
+    if (dev >= 0 && dev < DRK_MAX_DEVICES) {
+      cus = cu_count[dev].load(std::memory_order_relaxed);
+      if (cus == 0) {
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        cu_count[dev].store(cus, std::memory_order_relaxed);
+      }
+    }
+  }
+  const int per = (int)((ntiles + cus - 1) / cus);
+  const int nwg = (int)((ntiles + per - 1) / per);
+  hipLaunchKernelGGL(k_conv_x3, dim3(nwg), dim3(512), 0, (hipStream_t)stream, a, per, (int)ntiles);
   DRK_CHECK_LAUNCH();
   return DRK_OK;
 }

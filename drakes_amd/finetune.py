@@ -36,7 +36,8 @@ def ddpm_update_finetune_gradient(model, x, t, dt, copy_flag_temp, return_proces
         sig = sig[:1]                                  # one shared value (all rows are equal)
     if seed is None and uniforms is None:
         seed = model._draw_seed()
-    logits = autograd.backbone_with_grad(model.backbone, x, sig, model._soft_dtype() == 'bf16')
+    model.backbone.train_dtype = model._soft_dtype()
+    logits = autograd.backbone_with_grad(model.backbone, x, sig, model._soft_dtype())
     x_next, flag = autograd.soft_step_with_grad(logits, x, float(mct[0]), float(mcs[0]),
                                                 float(model.config.finetuning.gumbel_softmax_temp), copy_flag_temp,
                                                 seed or 0, step, sample_offset, uniforms, mc_rows)
@@ -102,7 +103,7 @@ def sample_finetune_gradient(model, num_steps=None, eps=1e-5, eval_sp_size=None,
             if x.ndim == 2:
                 x = F.one_hot(x, num_classes=model.vocab_size).to(torch.float32)
             sig = torch.full((1,), sigma_t if model.time_conditioning else 0.0, dtype=torch.float32, device=dev)
-            logits = autograd.backbone_with_grad(bb, x, sig, soft_bf16)
+            logits = autograd.backbone_with_grad(bb, x, sig, bb.train_dtype)
             last_x = x
             model._soft_logits_cache[id(x)] = (x, logits, bb._weights_key())
             x, copy_flag = autograd.soft_step_with_grad(logits, x, mc_t, mc_s, temp, copy_flag_temp, seed, i,

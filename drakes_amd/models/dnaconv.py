@@ -178,8 +178,12 @@ class CNNModel(nn.Module):
         if getattr(self, '_x3', None) is None or key != self._x3_key:
             with torch.no_grad():
                 P = {k: self.wide(k, v.detach()) for k, v in self.named_parameters()}
-                self._x3 = {'conv_w3': [ops.pack_conv_weight_x3(P[f'convs.{i}.weight']) for i in range(self.num_layers)],
-                            'head0_w3': ops.pack_conv_weight_x3(P['final_conv.0.weight'])}
+                n = self.num_layers
+                self._x3 = {'conv_w3': [ops.pack_conv_weight_x3(P[f'convs.{i}.weight']) for i in range(n)],
+                            'head0_w3': ops.pack_conv_weight_x3(P['final_conv.0.weight']),
+                            # input-gradient weights (autograd): weight.transpose(0,1).flip(2)
+                            'conv_w3T': [ops.pack_conv_weight_x3(P[f'convs.{i}.weight'].transpose(0, 1).flip(2)) for i in range(n)],
+                            'head0_w3T': ops.pack_conv_weight_x3(P['final_conv.0.weight'].transpose(0, 1))}
             self._x3_key = key
         return self._x3
 
@@ -223,6 +227,6 @@ class CNNModel(nn.Module):
             seq = seq.long()
         if torch.is_grad_enabled() and (seq.requires_grad or any(p.requires_grad for p in self.parameters())):
             from ..autograd import backbone_with_grad
-            return backbone_with_grad(self, seq.contiguous(), t.to(torch.float32), getattr(self, 'train_dtype', 'fp32') == 'bf16')
+            return backbone_with_grad(self, seq.contiguous(), t.to(torch.float32), getattr(self, 'train_dtype', 'fp32'))
         tbias = self.time_bias(t.to(torch.float32))
         return self.forward_f32(seq.contiguous(), tbias, tbias.stride(0))

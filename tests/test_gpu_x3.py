@@ -81,3 +81,49 @@ def test_x3_sample_tokens_equal_the_fixtures(dev, det_sd, gpu_model):
         want = torch.from_numpy(g['tokens'])
         toks = m._sample(eval_sp_size=want.shape[0], seed=int(g['useed'])).cpu()
         assert (toks != want).float().mean().item() == 0.0, name
+
+
+def test_x3_gradients_vs_oracle(dev, det_sd):
+    """hip_soft_dtype = 'bf16x3': forward and input-gradient convolutions on drk_conv_fwd_x3, weight gradients exact fp32:
+    parameter gradients against the oracle's autograd at the fp32 bar (2e-3 of each tensor's max)."""
+    from oracle import drakes_oracle as O
+    from test_gpu_finetune import _check_param_grads, _input_away_from_relu_kinks, _oracle_grads
+    B, L = 2, 45
+    m = drakes_amd.Diffusion(drakes_amd.default_config(length=L, time_conditioning=True)).to(dev)
+    m.load_state_dict(det_sd)
+    sigma = torch.tensor([0.3, 4.0])
+    x, gen = _input_away_from_relu_kinks(det_sd, B, L, True, sigma, 5)
+    Gm = torch.from_numpy(gen.standard_normal((B, L, 5)).astype(np.float32))
+    xo = x.clone().requires_grad_()
+    sdg = _oracle_grads(det_sd, lambda sd: (O.cnn_forward(sd, xo, sigma) * Gm).sum())
+    xg = x.to(dev).requires_grad_()
+    m.backbone.train_dtype = 'bf16x3'
+    (m.backbone(xg, sigma.to(dev)) * Gm.to(dev)).sum().backward()
+    print('worst parameter gradient error (bf16x3):', _check_param_grads(m, sdg))
+    assert float((xg.grad.cpu() - xo.grad).abs().max()) / float(xo.grad.abs().max()) < 2e-3
+
+
+def test_x3_sample_finetune_gradient_golden(dev, det_sd):
+    """Fixture F5 (16 steps, K = 6) with hip_dtype = 'bf16x3': outputs and the six gradient tensors at the fp32 path's bars."""
+    g = load_golden('f5_finetune_s16k6.npz')
+    steps, trunc, temp = int(g['steps']), int(g['trunc']), float(g['temp'])
+    m = drakes_amd.Diffusion(drakes_amd.default_config(steps=steps)).to(dev)
+    m.load_state_dict(det_sd)
+    m.train()
+    m.hip_dtype = 'bf16x3'
+    m.config.finetuning.truncate_steps = trunc
+    m.config.finetuning.gumbel_softmax_temp = temp
+    out, lx, ct, mct, cf = m._sample_finetune_gradient(eval_sp_size=2, seed=int(g['useed']))
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g['sample'], rtol=1e-4, atol=2e-4)
+    np.testing.assert_allclose(lx[-1].detach().cpu().numpy(), g['last_x_final'], rtol=1e-4, atol=2e-4)
+    rw = torch.from_numpy(g['reward_w']).to(dev)
+    (-(out.permute(0, 2, 1) * rw).sum((1, 2)).mean()).backward()
+    params = dict(m.named_parameters())
+    for key in g.files:
+        if key.startswith('grad_backbone'):
+            ref = torch.from_numpy(g[key])
+            got = params[key[len('grad_'):]].grad.cpu()[:ref.shape[0]]
+            e = (got - ref).abs().max().item() / max(ref.abs().max().item(), 1e-12)
+            assert e < 5e-3, (key, e)
+    gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m.parameters() if p.grad is not None)).item()
+    assert abs(gn - float(g['grad_norm'])) <= 2e-3 * float(g['grad_norm'])

@@ -57,7 +57,7 @@ def main():
     ap.add_argument('--length', type=int, default=200)
     ap.add_argument('--reps', type=int, default=3)
     ap.add_argument('--json', default=None)
-    ap.add_argument('--dtype', default='fp32', choices=['fp32', 'bf16'], help="hip_dtype: 'bf16' = fused hard phase + bf16 soft steps and backward")
+    ap.add_argument('--dtype', default='fp32', choices=['fp32', 'bf16x3', 'bf16'], help="hip_dtype: 'bf16' = fused hard phase + bf16 soft steps and backward; 'bf16x3' = fp32-grade convolutions on bf16 MFMA")
     ap.add_argument('--loop', action='store_true', help='time whole fine_tune optimizer steps (sampling + reward + KL over all steps + Adam)')
     a = ap.parse_args()
     if a.loop:
