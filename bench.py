@@ -48,14 +48,14 @@ PEAK = {'bf16': 2500.0, 'fp32': 157.3}            # TFLOP/s dense MFMA, MI355X_M
 # for 16-B-per-lane loads on gfx950): tools/pmc_traffic.sh.  A recorded measurement (a process cannot collect PMC
 # counters on itself): it names the library version it was taken on and is printed ONLY when drk_version() still is
 # that version — a changed kernel reports traffic null until the passes are re-run.
-PMC_TRAFFIC = {('bf16', 1024): {'drk_version': 201,
-                                'bytes_per_launch': 27219483200.0, 'fetch_bytes': 26716479232.0, 'write_bytes': 503003968.0,
+PMC_TRAFFIC = {('bf16', 1024): {'drk_version': 202,
+                                'bytes_per_launch': 27219523648.0, 'fetch_bytes': 26716522496.0, 'write_bytes': 503001152.0,
                                 'algorithmic_bytes': 7.6e6,
                                 'note': 'L2-to-fabric requests; Infinity-Cache hits are counted: the 5.9 MB bf16 weight '
                                         'stream outgrows a 4 MB per-XCD L2 and is re-fetched from the 256 MB Infinity '
                                         'Cache; 0.25 TB/s = 3.1 % of HBM peak, the launch is MFMA-bound; the writes are '
                                         'scratch spills of the per-forward stem/head block (152 B/lane), tokens out are 1.6 MB',
-                                'source': 'profiles/r2_bf16_v10_pmc_traffic.json'}}
+                                'source': 'profiles/r2_bf16_v202_pmc_traffic.json'}}
 
 
 def _median(v):
@@ -225,9 +225,10 @@ def workload_sample(args, model, rank, world, barrier):
     return out, elapsed
 
 
-def secondary_fp32(model, B=1024):
-    """The token-exact fp32 path on the same workload, in the same run: one warm-up call, one timed call."""
-    model.hip_dtype = 'fp32'
+def secondary_fp32(model, B=1024, dtype='fp32'):
+    """The token-exact fp32 path (or 'bf16x3': the same loop with fp32-grade convolutions on the bf16 matrix cores) on the
+    same workload, in the same run: one warm-up call, one timed call."""
+    model.hip_dtype = dtype
     try:
         model._sample(eval_sp_size=64, seed=1)
         torch.cuda.synchronize()
@@ -385,8 +386,11 @@ def main():
             collective = _rccl_world1_probe(dev)
             if args.workload == 'sample' and args.dtype == 'bf16' and not args.no_secondary:
                 line['secondary'] = {'fp32_token_exact_seq_per_s': secondary_fp32(model),
+                                     'bf16x3_fp32_grade_seq_per_s': secondary_fp32(model, dtype='bf16x3'),
                                      'note': 'same workload (B=1024, 128 steps + noise removal) on the exact-fp32 kernels, '
-                                             'whose tokens equal the reference bit for bit; 1 warm-up + 1 timed call'}
+                                             'whose tokens equal the reference bit for bit, and with their convolutions '
+                                             'at fp32 grade on the bf16 matrix cores (three bf16 planes per operand; tokens '
+                                             'equal on the fixtures); 1 warm-up + 1 timed call each'}
             if not args.no_cpu_baseline and args.workload == 'sample':      # rank 0, N=1 only
                 line['cpu_baseline'] = cpu_baseline()
         line['collective'] = collective
