@@ -285,6 +285,208 @@ __global__ void __launch_bounds__(512, 2) k_conv_x3(const X3Args a, const int ti
   }
 }
 
+// ---- small dilations (96 + 8 * dilation <= 128 rows: dilation <= 4 with nine taps; 1x1 convs): the tile's rows and
+// their halo are split and parked ONCE, a tap is a row offset into that image, and a lane whose shifted position leaves
+// [0, L) reads an all-zero row instead.  No staging, split or barrier inside the tap loop; the next tile's rows are in
+// flight in registers under the whole tap loop and are parked after the two halves have met.
+#define X3H_ROWS 128                                 // image rows: 96 + 2 * halo
+#define X3H_ZERO (X3H_ROWS * X3_ROWB)                // the all-zero row
+#define X3H_SMEM (X3H_ZERO + X3_ROWB)                // 101 136 B
+__global__ void __launch_bounds__(512, 2) k_conv_x3_halo(const X3Args a, const int tiles_per_wg, const int ntiles) {
+  __shared__ __attribute__((aligned(16))) char smem[X3H_SMEM];
+  const int t_begin = blockIdx.x * tiles_per_wg;
+  const int t_end = t_begin + tiles_per_wg < ntiles ? t_begin + tiles_per_wg : ntiles;
+  if (t_begin >= t_end) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int ct = __builtin_amdgcn_readfirstlane((tid >> 6) & 3);
+  const int kh = __builtin_amdgcn_readfirstlane(tid >> 8);
+  const int n = lane & 15, g = lane >> 4;
+  const int ch0 = 32 * ct + 4 * g;
+  const int L = a.L;
+  const int center = a.taps / 2;
+  const int last_tap = a.taps - 1 - a.first_tap;
+  const int halo = center * a.dil;                       // 96 + 2 * halo <= X3H_ROWS, checked by the entry point
+  const int rows_total = X3_ROWS + 2 * halo;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  // staging role: image rows srow + 16 i (i < 8), 16-byte chunk scol of the 512-byte row
+  const int srow = tid >> 5, scol = tid & 31;
+  f32x4 stage[8];
+  unsigned live = 0;
+  auto fetch = [&](long r0) {
+    live = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const long row = r0 - halo + srow + 16 * i;
+      const bool ok = row >= 0 && row < a.M;               // (rows of a neighbouring sequence are masked at the read)
+      live |= ok ? (1u << i) : 0u;
+      const long src = row < 0 ? 0 : row >= a.M ? a.M - 1 : row;
+      stage[i] = *(const f32x4*)(a.h + src * DRK_C + 4 * scol);
+    }
+  };
+  auto park = [&]() {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (srow + 16 * i < rows_total) {
+        bf16v4 q0, q1, q2;
+        split3((live >> i) & 1 ? stage[i] : zero4, q0, q1, q2);
+        char* d = smem + (srow + 16 * i) * X3_ROWB + 8 * scol;
+        *(bf16v4*)(d) = q0;
+        *(bf16v4*)(d + 256) = q1;
+        *(bf16v4*)(d + 512) = q2;
+      }
+    }
+  };
+  if (tid < X3_ROWB / 16) *(f32x4*)(smem + X3H_ZERO + 16 * tid) = zero4;
+
+  const char* wlane = a.w3 + (2 * kh) * X3_KSTEP_BYTES + ct * (2 * X3_SUB_BYTES) + lane * 16;
+  bf16v8 wa[2][3][2];
+  auto load_w = [&](int slot, int tap, int ksl) {
+    const char* p = wlane + (long)tap * X3_TAP_BYTES + ksl * X3_KSTEP_BYTES;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+      wa[slot][pl][0] = *(const bf16v8*)(p + pl * X3_PLANE_BYTES);
+      wa[slot][pl][1] = *(const bf16v8*)(p + pl * X3_PLANE_BYTES + X3_SUB_BYTES);
+    }
+  };
+  load_w(0, a.first_tap, 0);
+  fetch((long)t_begin * X3_ROWS);
+  park();
+  __syncthreads();
+
+  const int koff = 2 * (64 * (g & 1) + 32 * (g >> 1) + 16 * kh);     // this lane's 16-byte chunk of a plane, k-step 2 kh
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    const long r0 = (long)tile * X3_ROWS;
+    const bool next_tile = tile + 1 < t_end;
+    const unsigned p0 = (unsigned)(r0 % L);
+    int pos[X3_NT];
+#pragma unroll
+    for (int t = 0; t < X3_NT; ++t) pos[t] = (int)((p0 + 16 * t + n) % (unsigned)L);
+    f32x4 acc[X3_NT][2];
+#pragma unroll
+    for (int t = 0; t < X3_NT; ++t) {
+      acc[t][0] = zero4;
+      acc[t][1] = zero4;
+    }
+    load_w(1, a.first_tap, 1);
+    if (next_tile) fetch(r0 + X3_ROWS);                    // in flight under the whole tap loop
+    for (int tap = a.first_tap; tap <= last_tap; ++tap) {
+      const bool more = tap < last_tap;
+      const int sh = (tap - center) * a.dil;
+      int addr[X3_NT];
+#pragma unroll
+      for (int t = 0; t < X3_NT; ++t)
+        addr[t] = (unsigned)(pos[t] + sh) < (unsigned)L ? (halo + 16 * t + n + sh) * X3_ROWB + koff : X3H_ZERO + koff;
+#pragma unroll
+      for (int ksl = 0; ksl < 2; ++ksl) {
+        if (tap > a.first_tap || ksl == 1) {               // (the first k-step's successor was requested ahead of the rows)
+          if (ksl == 0) load_w(1, tap, 1);
+          else load_w(0, more ? tap + 1 : a.first_tap, 0);
+        }
+        bf16v8 b0 = *(const bf16v8*)(smem + addr[0] + 16 * ksl), b1 = *(const bf16v8*)(smem + addr[0] + 16 * ksl + 256),
+               b2 = *(const bf16v8*)(smem + addr[0] + 16 * ksl + 512);
+        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+#pragma unroll
+        for (int t = 0; t < X3_NT; ++t) {
+          const bf16v8 c0 = b0, c1 = b1, c2 = b2;
+          if (t + 1 < X3_NT) {
+            const char* nb = smem + addr[t + 1] + 16 * ksl;
+            b0 = *(const bf16v8*)(nb);
+            b1 = *(const bf16v8*)(nb + 256);
+            b2 = *(const bf16v8*)(nb + 512);
+          }
+          f32x4 e0 = acc[t][0], e1 = acc[t][1];
+          e0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ksl][2][0], c0, e0, 0, 0, 0);
+          e1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ksl][2][1], c0, e1, 0, 0, 0);
+          e0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ksl][1][0], c1, e0, 0, 0, 0);
+          e1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ksl][1][1], c1, e1, 0, 0, 0);
+          e0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ksl][0][0], c2, e0, 0, 0, 0);
+          e1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ksl][0][1], c2, e1, 0, 0, 0);
+          e0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ksl][1][0], c0, e0, 0, 0, 0);
+          e1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ksl][1][1], c0, e1, 0, 0, 0);
+          e0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ksl][0][0], c1, e0, 0, 0, 0);
+          e1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ksl][0][1], c1, e1, 0, 0, 0);
+          e0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ksl][0][0], c0, e0, 0, 0, 0);
+          e1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ksl][0][1], c0, e1, 0, 0, 0);
+          acc[t][0] = e0;
+          acc[t][1] = e1;
+          if (t + 1 < X3_NT) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+        }
+      }
+    }
+    __syncthreads();           // every wave is past its reads of the image: it carries the exchange now
+    constexpr int HT = X3_NT / 2;
+    f32x4 mine[HT][2];
+    {
+      f32x4* const xw = (f32x4*)smem + (tid >> 6) * (2 * HT * 64) + lane;
+      const f32x4* const xr = (const f32x4*)smem + ((tid >> 6) ^ 4) * (2 * HT * 64) + lane;
+      if (kh == 0) {
+#pragma unroll
+        for (int t = 0; t < HT; ++t) {
+          xw[(2 * t) * 64] = acc[HT + t][0];
+          xw[(2 * t + 1) * 64] = acc[HT + t][1];
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < HT; ++t) {
+          xw[(2 * t) * 64] = acc[t][0];
+          xw[(2 * t + 1) * 64] = acc[t][1];
+        }
+      }
+      __syncthreads();
+      if (kh == 0) {
+#pragma unroll
+        for (int t = 0; t < HT; ++t) {
+          mine[t][0] = acc[t][0] + xr[(2 * t) * 64];
+          mine[t][1] = acc[t][1] + xr[(2 * t + 1) * 64];
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < HT; ++t) {
+          mine[t][0] = xr[(2 * t) * 64] + acc[HT + t][0];
+          mine[t][1] = xr[(2 * t + 1) * 64] + acc[HT + t][1];
+        }
+      }
+    }
+    // the residual is requested before the next tile's rows are split and parked, and added after
+    f32x4 res[HT][2];
+#pragma unroll
+    for (int t = 0; t < HT; ++t) {
+      long row = r0 + 16 * HT * kh + 16 * t + n;
+      row = row < a.M ? row : a.M - 1;
+      res[t][0] = a.resid ? *(const f32x4*)(a.resid + row * DRK_C + ch0) : zero4;
+      res[t][1] = a.resid ? *(const f32x4*)(a.resid + row * DRK_C + ch0 + 16) : zero4;
+    }
+    if (next_tile) {
+      __syncthreads();         // the exchange has been read: the image takes the next tile's rows
+      park();
+    }
+    const f32x4 cb0 = a.bias ? *(const f32x4*)(a.bias + ch0) : zero4, cb1 = a.bias ? *(const f32x4*)(a.bias + ch0 + 16) : zero4;
+#pragma unroll
+    for (int t = 0; t < HT; ++t) {
+      const long row = r0 + 16 * HT * kh + 16 * t + n;
+      if (row >= a.M) continue;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        f32x4 r = mine[t][s] + (s ? cb1 : cb0);
+        if (a.relu) {
+          if (a.mask) {
+            const unsigned m = (r[0] > 0.f ? 1u : 0u) | (r[1] > 0.f ? 0x100u : 0u) | (r[2] > 0.f ? 0x10000u : 0u) |
+                               (r[3] > 0.f ? 0x1000000u : 0u);
+            *(unsigned*)(a.mask + row * DRK_C + ch0 + 16 * s) = m;
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) r[i] = fmaxf(r[i], 0.f);
+        }
+        r += res[t][s];
+        *(f32x4*)(a.out + row * DRK_C + ch0 + 16 * s) = r;
+      }
+    }
+    if (next_tile) __syncthreads();   // the parked rows are visible
+  }
+}
+
 extern "C" int drk_conv_fwd_x3(const float* h, const void* w3, const float* bias, const float* resid, float* out,
                                unsigned char* relu_mask, int B, int L, int taps, int dilation, int relu, void* stream) {
   DRK_SHAPE_GUARD("drk_conv_fwd_x3");
@@ -314,6 +516,11 @@ extern "C" int drk_conv_fwd_x3(const float* h, const void* w3, const float* bias
   }
   const int per = (int)((ntiles + cus - 1) / cus);
   const int nwg = (int)((ntiles + per - 1) / per);
+#ifndef X3_NO_HALO
+  if (X3_ROWS + 2 * center * dilation <= X3H_ROWS)
+    hipLaunchKernelGGL(k_conv_x3_halo, dim3(nwg), dim3(512), 0, (hipStream_t)stream, a, per, (int)ntiles);
+  else
+#endif
   hipLaunchKernelGGL(k_conv_x3, dim3(nwg), dim3(512), 0, (hipStream_t)stream, a, per, (int)ntiles);
   DRK_CHECK_LAUNCH();
   return DRK_OK;
