@@ -415,6 +415,15 @@ __global__ void __launch_bounds__(512, 2) k_conv_x3_halo(const X3Args a, const i
         }
       }
     }
+    // the residual is requested as soon as the last MFMA has issued: it arrives under the exchange and the parking
+    f32x4 res[X3_NT / 2][2];
+#pragma unroll
+    for (int t = 0; t < X3_NT / 2; ++t) {
+      long row = r0 + 16 * (X3_NT / 2) * kh + 16 * t + n;
+      row = row < a.M ? row : a.M - 1;
+      res[t][0] = a.resid ? *(const f32x4*)(a.resid + row * DRK_C + ch0) : zero4;
+      res[t][1] = a.resid ? *(const f32x4*)(a.resid + row * DRK_C + ch0 + 16) : zero4;
+    }
     __syncthreads();           // every wave is past its reads of the image: it carries the exchange now
     constexpr int HT = X3_NT / 2;
     f32x4 mine[HT][2];
@@ -448,15 +457,6 @@ __global__ void __launch_bounds__(512, 2) k_conv_x3_halo(const X3Args a, const i
           mine[t][1] = xr[(2 * t + 1) * 64] + acc[HT + t][1];
         }
       }
-    }
-    // the residual is requested before the next tile's rows are split and parked, and added after
-    f32x4 res[HT][2];
-#pragma unroll
-    for (int t = 0; t < HT; ++t) {
-      long row = r0 + 16 * HT * kh + 16 * t + n;
-      row = row < a.M ? row : a.M - 1;
-      res[t][0] = a.resid ? *(const f32x4*)(a.resid + row * DRK_C + ch0) : zero4;
-      res[t][1] = a.resid ? *(const f32x4*)(a.resid + row * DRK_C + ch0 + 16) : zero4;
     }
     if (next_tile) {
       __syncthreads();         // the exchange has been read: the image takes the next tile's rows
