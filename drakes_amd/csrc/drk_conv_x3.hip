@@ -289,10 +289,16 @@ __global__ void __launch_bounds__(512, 2) k_conv_x3(const X3Args a, const int ti
 // their halo are split and parked ONCE, a tap is a row offset into that image, and a lane whose shifted position leaves
 // [0, L) reads an all-zero row instead.  No staging, split or barrier inside the tap loop; the next tile's rows are in
 // flight in registers under the whole tap loop and are parked after the two halves have met.
-#define X3H_ROWS 128                                 // image rows: 96 + 2 * halo
-#define X3H_ZERO (X3H_ROWS * X3_ROWB)                // the all-zero row
-#define X3H_SMEM (X3H_ZERO + X3_ROWB)                // 101 136 B
+// NT = 16-row tiles per workgroup tile: 6 (96 rows, as the per-tap kernel) or 8 (128 rows: for launches of few tiles —
+// the fine-tune shapes — where 128-row tiles need one round of the chip and 96-row tiles two).  Image rows: 16 NT + 32.
+#define X3H_HALO_MAX 16
+template <int NT>
 __global__ void __launch_bounds__(512, 2) k_conv_x3_halo(const X3Args a, const int tiles_per_wg, const int ntiles) {
+  constexpr int TROWS = 16 * NT;                         // rows per tile
+  constexpr int X3H_ROWS = TROWS + 2 * X3H_HALO_MAX;     // image rows
+  constexpr int X3H_ZERO = X3H_ROWS * X3_ROWB;           // the all-zero row
+  constexpr int X3H_SMEM = X3H_ZERO + X3_ROWB;           // 101 136 B (NT = 6), 126 224 B (NT = 8)
+  constexpr int NST = X3H_ROWS / 16;                     // staging passes of 16 rows
   __shared__ __attribute__((aligned(16))) char smem[X3H_SMEM];
   const int t_begin = blockIdx.x * tiles_per_wg;
   const int t_end = t_begin + tiles_per_wg < ntiles ? t_begin + tiles_per_wg : ntiles;
@@ -305,18 +311,18 @@ __global__ void __launch_bounds__(512, 2) k_conv_x3_halo(const X3Args a, const i
   const int L = a.L;
   const int center = a.taps / 2;
   const int last_tap = a.taps - 1 - a.first_tap;
-  const int halo = center * a.dil;                       // 96 + 2 * halo <= X3H_ROWS, checked by the entry point
-  const int rows_total = X3_ROWS + 2 * halo;
+  const int halo = center * a.dil;                       // <= X3H_HALO_MAX, checked by the entry point
+  const int rows_total = TROWS + 2 * halo;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
-  // staging role: image rows srow + 16 i (i < 8), 16-byte chunk scol of the 512-byte row
+  // staging role: image rows srow + 16 i (i < NST), 16-byte chunk scol of the 512-byte row
   const int srow = tid >> 5, scol = tid & 31;
-  f32x4 stage[8];
+  f32x4 stage[NST];
   unsigned live = 0;
   auto fetch = [&](long r0) {
     live = 0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < NST; ++i) {
       const long row = r0 - halo + srow + 16 * i;
       const bool ok = row >= 0 && row < a.M;               // (rows of a neighbouring sequence are masked at the read)
       live |= ok ? (1u << i) : 0u;
@@ -326,7 +332,7 @@ __global__ void __launch_bounds__(512, 2) k_conv_x3_halo(const X3Args a, const i
   };
   auto park = [&]() {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < NST; ++i) {
       if (srow + 16 * i < rows_total) {
         bf16v4 q0, q1, q2;
         split3((live >> i) & 1 ? stage[i] : zero4, q0, q1, q2);
@@ -350,32 +356,32 @@ __global__ void __launch_bounds__(512, 2) k_conv_x3_halo(const X3Args a, const i
     }
   };
   load_w(0, a.first_tap, 0);
-  fetch((long)t_begin * X3_ROWS);
+  fetch((long)t_begin * TROWS);
   park();
   __syncthreads();
 
   const int koff = 2 * (64 * (g & 1) + 32 * (g >> 1) + 16 * kh);     // this lane's 16-byte chunk of a plane, k-step 2 kh
   for (int tile = t_begin; tile < t_end; ++tile) {
-    const long r0 = (long)tile * X3_ROWS;
+    const long r0 = (long)tile * TROWS;
     const bool next_tile = tile + 1 < t_end;
     const unsigned p0 = (unsigned)(r0 % L);
-    int pos[X3_NT];
+    int pos[NT];
 #pragma unroll
-    for (int t = 0; t < X3_NT; ++t) pos[t] = (int)((p0 + 16 * t + n) % (unsigned)L);
-    f32x4 acc[X3_NT][2];
+    for (int t = 0; t < NT; ++t) pos[t] = (int)((p0 + 16 * t + n) % (unsigned)L);
+    f32x4 acc[NT][2];
 #pragma unroll
-    for (int t = 0; t < X3_NT; ++t) {
+    for (int t = 0; t < NT; ++t) {
       acc[t][0] = zero4;
       acc[t][1] = zero4;
     }
     load_w(1, a.first_tap, 1);
-    if (next_tile) fetch(r0 + X3_ROWS);                    // in flight under the whole tap loop
+    if (next_tile) fetch(r0 + TROWS);                    // in flight under the whole tap loop
     for (int tap = a.first_tap; tap <= last_tap; ++tap) {
       const bool more = tap < last_tap;
       const int sh = (tap - center) * a.dil;
-      int addr[X3_NT];
+      int addr[NT];
 #pragma unroll
-      for (int t = 0; t < X3_NT; ++t)
+      for (int t = 0; t < NT; ++t)
         addr[t] = (unsigned)(pos[t] + sh) < (unsigned)L ? (halo + 16 * t + n + sh) * X3_ROWB + koff : X3H_ZERO + koff;
 #pragma unroll
       for (int ksl = 0; ksl < 2; ++ksl) {
@@ -387,9 +393,9 @@ __global__ void __launch_bounds__(512, 2) k_conv_x3_halo(const X3Args a, const i
                b2 = *(const bf16v8*)(smem + addr[0] + 16 * ksl + 512);
         __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
 #pragma unroll
-        for (int t = 0; t < X3_NT; ++t) {
+        for (int t = 0; t < NT; ++t) {
           const bf16v8 c0 = b0, c1 = b1, c2 = b2;
-          if (t + 1 < X3_NT) {
+          if (t + 1 < NT) {
             const char* nb = smem + addr[t + 1] + 16 * ksl;
             b0 = *(const bf16v8*)(nb);
             b1 = *(const bf16v8*)(nb + 256);
@@ -410,22 +416,22 @@ __global__ void __launch_bounds__(512, 2) k_conv_x3_halo(const X3Args a, const i
           e1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ksl][0][1], c0, e1, 0, 0, 0);
           acc[t][0] = e0;
           acc[t][1] = e1;
-          if (t + 1 < X3_NT) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+          if (t + 1 < NT) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
           __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
         }
       }
     }
     // the residual is requested as soon as the last MFMA has issued: it arrives under the exchange and the parking
-    f32x4 res[X3_NT / 2][2];
+    f32x4 res[NT / 2][2];
 #pragma unroll
-    for (int t = 0; t < X3_NT / 2; ++t) {
-      long row = r0 + 16 * (X3_NT / 2) * kh + 16 * t + n;
+    for (int t = 0; t < NT / 2; ++t) {
+      long row = r0 + 16 * (NT / 2) * kh + 16 * t + n;
       row = row < a.M ? row : a.M - 1;
       res[t][0] = a.resid ? *(const f32x4*)(a.resid + row * DRK_C + ch0) : zero4;
       res[t][1] = a.resid ? *(const f32x4*)(a.resid + row * DRK_C + ch0 + 16) : zero4;
     }
     __syncthreads();           // every wave is past its reads of the image: it carries the exchange now
-    constexpr int HT = X3_NT / 2;
+    constexpr int HT = NT / 2;
     f32x4 mine[HT][2];
     {
       f32x4* const xw = (f32x4*)smem + (tid >> 6) * (2 * HT * 64) + lane;
@@ -501,8 +507,6 @@ extern "C" int drk_conv_fwd_x3(const float* h, const void* w3, const float* bias
   int reach = center;                      // taps whose shift is >= L read only padding: skipped
   if (dilation > 0 && (L - 1) / dilation < reach) reach = (L - 1) / dilation;
   a.first_tap = center - reach;
-  const long ntiles = (a.M + X3_ROWS - 1) / X3_ROWS;
-  if (ntiles >= (1L << 30)) return drk_set_error_msg(DRK_EINVAL, "drk_conv_fwd_x3: too many rows");
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) {
     static std::atomic<int> cu_count[DRK_MAX_DEVICES];
@@ -514,14 +518,20 @@ extern "C" int drk_conv_fwd_x3(const float* h, const void* w3, const float* bias
       }
     }
   }
+  if (a.M >= (1L << 34)) return drk_set_error_msg(DRK_EINVAL, "drk_conv_fwd_x3: too many rows");
+  const long t6 = (a.M + 95) / 96, t8 = (a.M + 127) / 128;
+  const bool halo_form = center * dilation <= X3H_HALO_MAX;
+  // 128-row tiles where they take fewer row-rounds of the chip (few tiles: one round of 128 rows instead of two of 96)
+  const bool big = halo_form && ((t8 + cus - 1) / cus) * 8 < ((t6 + cus - 1) / cus) * 6;
+  const long ntiles = big ? t8 : t6;
   const int per = (int)((ntiles + cus - 1) / cus);
   const int nwg = (int)((ntiles + per - 1) / per);
-#ifndef X3_NO_HALO
-  if (X3_ROWS + 2 * center * dilation <= X3H_ROWS)
-    hipLaunchKernelGGL(k_conv_x3_halo, dim3(nwg), dim3(512), 0, (hipStream_t)stream, a, per, (int)ntiles);
+  if (big)
+    hipLaunchKernelGGL(k_conv_x3_halo<8>, dim3(nwg), dim3(512), 0, (hipStream_t)stream, a, per, (int)ntiles);
+  else if (halo_form)
+    hipLaunchKernelGGL(k_conv_x3_halo<6>, dim3(nwg), dim3(512), 0, (hipStream_t)stream, a, per, (int)ntiles);
   else
-#endif
-  hipLaunchKernelGGL(k_conv_x3, dim3(nwg), dim3(512), 0, (hipStream_t)stream, a, per, (int)ntiles);
+    hipLaunchKernelGGL(k_conv_x3, dim3(nwg), dim3(512), 0, (hipStream_t)stream, a, per, (int)ntiles);
   DRK_CHECK_LAUNCH();
   return DRK_OK;
 }
