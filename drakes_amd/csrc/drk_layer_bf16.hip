@@ -237,6 +237,17 @@ __global__ void __launch_bounds__(256, WGS) k_layer_bf16(const LayerArgs a) {
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   const f32x4 cb0 = a.bias ? *(const f32x4*)(a.bias + ch0) : zero4, cb1 = a.bias ? *(const f32x4*)(a.bias + ch0 + 16) : zero4;
   f32x4 x[LT_NT][2];
+  f32x4 late[PRE ? 1 : LT_NT][2];
+  if constexpr (!PRE) {   // every residual request before the first use and the first store (feat_out may be feat, so
+                          // the compiler cannot move a load above a store by itself): one round trip, not sixteen
+#pragma unroll
+    for (int t = 0; t < LT_NT; ++t) {
+      long row = r0 + 16 * t + pn;
+      row = row < a.M ? row : a.M - 1;
+      late[t][0] = a.feat ? *(const f32x4*)(a.feat + row * DRK_C + ch0) : zero4;
+      late[t][1] = a.feat ? *(const f32x4*)(a.feat + row * DRK_C + ch0 + 16) : zero4;
+    }
+  }
 #pragma unroll
   for (int t = 0; t < LT_NT; ++t) {
     const long row = r0 + 16 * t + pn;
@@ -254,11 +265,8 @@ __global__ void __launch_bounds__(256, WGS) k_layer_bf16(const LayerArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) r[i] = fmaxf(r[i], 0.f);
       }
-      if constexpr (PRE) {
-        r += res[t][s];
-      } else {
-        if (a.feat && ok) r += *(const f32x4*)(a.feat + row * DRK_C + ch0 + 16 * s);
-      }
+      if constexpr (PRE) r += res[t][s];
+      else r += late[t][s];
       if (ok) *(f32x4*)(a.feat_out + row * DRK_C + ch0 + 16 * s) = r;
       x[t][s] = r;
     }

@@ -62,7 +62,16 @@ __global__ void __launch_bounds__(256) k_colsum128(const float* __restrict__ x, 
 // dfeat_out = dxin + g_resid (the gradient arriving through the residual branch); dxin is also stored
 // on its own for the time-bias gradient.  32 lanes per row; per-workgroup partial column sums in LDS,
 // then one atomic per column per workgroup.
-__global__ void __launch_bounds__(256) k_ln_bwd(const float* __restrict__ dh, const float* __restrict__ feat,
+#ifndef LNB_UNR
+#define LNB_UNR 4
+#endif
+// LNB_UNR: rows per half-wave and pass: all their loads are requested before the first use
+#define LNB_SLOTS 16                     // half-waves per workgroup (512 threads)
+#define LNB_PASS_ROWS (LNB_SLOTS * LNB_UNR)
+// `passes` passes of 64 rows per workgroup: the host sizes it so that the launch is about one workgroup per CU — the
+// column sums end in one float atomic per column and workgroup on the SAME 128 addresses, and those serialise (400
+// workgroups of 64 rows: 24 us at 25 600 rows, most of it the atomics; 800 of 32 rows: 29 us).
+__global__ void __launch_bounds__(512) k_ln_bwd(const float* __restrict__ dh, const float* __restrict__ feat,
                                                 const float* __restrict__ tbias, long tb_stride,
                                                 const float* __restrict__ gamma, const float* __restrict__ mean,
                                                 const float* __restrict__ rstd, const float* __restrict__ g_resid,
@@ -70,73 +79,80 @@ __global__ void __launch_bounds__(256) k_ln_bwd(const float* __restrict__ dh, co
                                                 float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                 float* __restrict__ dtb, const unsigned char* __restrict__ next_mask,
                                                 char* __restrict__ dc_next, float* __restrict__ dbias_next, long M, int L,
-                                                int width) {
-  __shared__ float pg[8][128], pb[8][128], px[8][128], pc[8][128];
+                                                int width, int passes) {
+  __shared__ float pg[LNB_SLOTS][128], pb[LNB_SLOTS][128], px[LNB_SLOTS][128], pc[LNB_SLOTS][128];
   const float inv = 1.0f / (float)width;   // width < 128: statistics over the first `width` channels (drk_ln_fwd)
   const int lr = threadIdx.x & 31, sub = threadIdx.x >> 5;
   const f32x4 gm = *(const f32x4*)(gamma + 4 * lr);
-  f32x4 ag = {0.f, 0.f, 0.f, 0.f}, ab = {0.f, 0.f, 0.f, 0.f}, ax = {0.f, 0.f, 0.f, 0.f}, ac = {0.f, 0.f, 0.f, 0.f};
-  for (long row = (long)blockIdx.x * 64 + sub; row < (long)blockIdx.x * 64 + 64 && row < M; row += 8) {
-    const long b = row / L;
-    f32x4 x = *(const f32x4*)(feat + row * DRK_C + 4 * lr);
-    if (tbias) x += *(const f32x4*)(tbias + b * tb_stride + 4 * lr);
-    const float mu = mean[row], rs = rstd[row];
-    const f32x4 xh = (x - mu) * rs;
-    const f32x4 d = *(const f32x4*)(dh + row * DRK_C + 4 * lr);
-    const f32x4 dyg = d * gm;
-    float s1 = (dyg[0] + dyg[1]) + (dyg[2] + dyg[3]);
-    float s2 = (dyg[0] * xh[0] + dyg[1] * xh[1]) + (dyg[2] * xh[2] + dyg[3] * xh[3]);
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 ag = zero4, ab = zero4, ax = zero4, ac = zero4;
+  for (int pass = 0; pass < passes; ++pass) {
+    const long base = ((long)blockIdx.x * passes + pass) * LNB_PASS_ROWS + sub;
+    if (base - sub >= M) break;
+    f32x4 xv[LNB_UNR], dv[LNB_UNR], gv[LNB_UNR];
+    float muv[LNB_UNR], rsv[LNB_UNR];
+    unsigned mkv[LNB_UNR];
 #pragma unroll
-    for (int o = 16; o >= 1; o >>= 1) {
-      s1 += __shfl_xor(s1, o);
-      s2 += __shfl_xor(s2, o);
+    for (int i = 0; i < LNB_UNR; ++i) {
+      const long row = base + LNB_SLOTS * i;
+      const long r = row < M ? row : M - 1;
+      xv[i] = *(const f32x4*)(feat + r * DRK_C + 4 * lr);
+      if (tbias) xv[i] += *(const f32x4*)(tbias + (r / L) * tb_stride + 4 * lr);
+      muv[i] = mean[r];
+      rsv[i] = rstd[r];
+      dv[i] = *(const f32x4*)(dh + r * DRK_C + 4 * lr);
+      gv[i] = g_resid ? *(const f32x4*)(g_resid + r * DRK_C + 4 * lr) : zero4;
+      mkv[i] = next_mask ? *(const unsigned*)(next_mask + r * DRK_C + 4 * lr) : 0u;
     }
-    const float m1 = s1 * inv, m2 = s2 * inv;
-    f32x4 dx = (dyg - m1 - xh * m2) * rs;
-    if (4 * lr >= width) dx = f32x4{0.f, 0.f, 0.f, 0.f};   // padding lanes carry no gradient
-    if (dxin) *(f32x4*)(dxin + row * DRK_C + 4 * lr) = dx;
-    f32x4 o = dx;
-    if (g_resid) o += *(const f32x4*)(g_resid + row * DRK_C + 4 * lr);
-    *(f32x4*)(dfeat + row * DRK_C + 4 * lr) = o;
-    if (next_mask) {   // the layer below: dc = bf16(dfeat * its ReLU mask), and the column sums = its conv bias gradient
-      const unsigned m = *(const unsigned*)(next_mask + row * DRK_C + 4 * lr);
-      const f32x4 v = {(m & 0xffu) ? o[0] : 0.f, (m & 0xff00u) ? o[1] : 0.f, (m & 0xff0000u) ? o[2] : 0.f, (m & 0xff000000u) ? o[3] : 0.f};
-      typedef __bf16 bf16v4_t __attribute__((ext_vector_type(4)));
-      bf16v4_t pk;
-      pk[0] = (__bf16)v[0]; pk[1] = (__bf16)v[1]; pk[2] = (__bf16)v[2]; pk[3] = (__bf16)v[3];
-      *(bf16v4_t*)(dc_next + row * 256 + 8 * lr) = pk;
-      ac += v;
+#pragma unroll
+    for (int i = 0; i < LNB_UNR; ++i) {
+      const long row = base + LNB_SLOTS * i;
+      if (row >= M) continue;               // (uniform over the half-wave: the shuffles below stay within it)
+      const float rs = rsv[i];
+      const f32x4 xh = (xv[i] - muv[i]) * rs;
+      const f32x4 d = dv[i];
+      const f32x4 dyg = d * gm;
+      float s1 = (dyg[0] + dyg[1]) + (dyg[2] + dyg[3]);
+      float s2 = (dyg[0] * xh[0] + dyg[1] * xh[1]) + (dyg[2] * xh[2] + dyg[3] * xh[3]);
+#pragma unroll
+      for (int o = 16; o >= 1; o >>= 1) {
+        s1 += __shfl_xor(s1, o);
+        s2 += __shfl_xor(s2, o);
+      }
+      const float m1 = s1 * inv, m2 = s2 * inv;
+      f32x4 dx = (dyg - m1 - xh * m2) * rs;
+      if (4 * lr >= width) dx = zero4;   // padding lanes carry no gradient
+      if (dxin) *(f32x4*)(dxin + row * DRK_C + 4 * lr) = dx;
+      const f32x4 o = dx + gv[i];
+      *(f32x4*)(dfeat + row * DRK_C + 4 * lr) = o;
+      if (next_mask) {   // the layer below: dc = bf16(dfeat * its ReLU mask), and the column sums = its conv bias gradient
+        const unsigned m = mkv[i];
+        const f32x4 v = {(m & 0xffu) ? o[0] : 0.f, (m & 0xff00u) ? o[1] : 0.f, (m & 0xff0000u) ? o[2] : 0.f, (m & 0xff000000u) ? o[3] : 0.f};
+        typedef __bf16 bf16v4_t __attribute__((ext_vector_type(4)));
+        bf16v4_t pk;
+        pk[0] = (__bf16)v[0]; pk[1] = (__bf16)v[1]; pk[2] = (__bf16)v[2]; pk[3] = (__bf16)v[3];
+        *(bf16v4_t*)(dc_next + row * 256 + 8 * lr) = pk;
+        ac += v;
+      }
+      ag += d * xh;
+      ab += d;
+      ax += dx;
     }
-    ag += d * xh;
-    ab += d;
-    ax += dx;
   }
   *(f32x4*)(&pg[sub][4 * lr]) = ag;
   *(f32x4*)(&pb[sub][4 * lr]) = ab;
   *(f32x4*)(&px[sub][4 * lr]) = ax;
   *(f32x4*)(&pc[sub][4 * lr]) = ac;
   __syncthreads();
-  if (threadIdx.x < 128) {
-    float sg = 0.f, sb = 0.f;
+  // four column sums x 128 columns = the 512 threads, one atomic each
+  const int col = threadIdx.x & 127, which = threadIdx.x >> 7;
+  float* const dst = which == 0 ? dgamma : which == 1 ? dbeta : which == 2 ? dtb : dbias_next;
+  if (dst) {
+    const float (*src)[128] = which == 0 ? pg : which == 1 ? pb : which == 2 ? px : pc;
+    float sum = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      sg += pg[k][threadIdx.x];
-      sb += pb[k][threadIdx.x];
-    }
-    atomicAdd(dgamma + threadIdx.x, sg);
-    atomicAdd(dbeta + threadIdx.x, sb);
-    if (dtb) {   // gradient of a time bias shared by the whole batch = column sum of dxin
-      float sx = 0.f;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) sx += px[k][threadIdx.x];
-      atomicAdd(dtb + threadIdx.x, sx);
-    }
-    if (dbias_next) {
-      float sc = 0.f;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) sc += pc[k][threadIdx.x];
-      atomicAdd(dbias_next + threadIdx.x, sc);
-    }
+    for (int k = 0; k < LNB_SLOTS; ++k) sum += src[k][col];
+    atomicAdd(dst + col, sum);
   }
 }
 
@@ -785,8 +801,15 @@ extern "C" int drk_ln_bwd(const float* dh, const float* feat, const float* tbias
   ARGCHECK(dh && feat && gamma && mean && rstd && dfeat && dgamma && dbeta, "drk_ln_bwd");
   ARGCHECK((!next_mask && !dc_next && !dbias_next) || (next_mask && dc_next), "drk_ln_bwd (next_mask and dc_next come together)");
   const long M = (long)B * L;
-  hipLaunchKernelGGL(k_ln_bwd, dim3((unsigned)((M + 63) / 64)), dim3(256), 0, (hipStream_t)stream, dh, feat, tbias,
-                     tbias_bstride, gamma, mean, rstd, g_resid, dxin, dfeat, dgamma, dbeta, dtbias_shared, next_mask, (char*)dc_next, dbias_next, M, L, width);
+#ifndef LNB_WGS
+#define LNB_WGS 256L
+#endif
+  long passes = (M + LNB_WGS * LNB_PASS_ROWS - 1) / (LNB_WGS * LNB_PASS_ROWS);   // about one workgroup per CU of an MI355X
+  passes = passes < 1 ? 1 : passes > 8 ? 8 : passes;
+  const long wg_rows = passes * LNB_PASS_ROWS;
+  hipLaunchKernelGGL(k_ln_bwd, dim3((unsigned)((M + wg_rows - 1) / wg_rows)), dim3(512), 0, (hipStream_t)stream, dh, feat, tbias,
+                     tbias_bstride, gamma, mean, rstd, g_resid, dxin, dfeat, dgamma, dbeta, dtbias_shared, next_mask,
+                     (char*)dc_next, dbias_next, M, L, width, (int)passes);
   DRK_CHECK_LAUNCH();
   return DRK_OK;
 }
