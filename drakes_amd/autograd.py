@@ -38,12 +38,56 @@ class _ZeroPool:
         return v
 
 
+def flat_params(bb):
+    """All parameters of the denoiser as ONE differentiable fp32 vector (torch.cat of the flattened parameters).
+
+    A caller that runs many differentiable forwards between two optimizer steps (the K Gumbel-softmax steps of
+    _sample_finetune_gradient) builds it once and hands it to backbone_with_grad(..., flat=...): every backward call
+    then returns ONE gradient vector, the engine adds K vectors instead of K x 129 tensors (one elementwise launch per
+    parameter and call: 6 300 launches, ~11 ms per pass at K = 50), and the cat's backward hands each parameter its
+    slice once.  The forward never reads the vector's values (it uses the packed kernel-layout copies): it only carries
+    the graph."""
+    return torch.cat([p.reshape(-1) for p in bb.parameters()])
+
+
+def _flat_grad(ctx, cls, g, pool, want_w, nb):
+    """The gradients in `g` (views of the backward call's zero pool) gathered into parameter order: one index_select.
+    The pool's layout is the same on every call of one configuration, so the index vector is built once."""
+    bb = ctx.bb
+    cache = bb.__dict__.setdefault('_flat_idx', {})
+    key = (cls, bool(want_w), int(nb), pool.buf.numel())
+    idx = cache.get(key)
+    if idx is None:
+        base, n = pool.buf.data_ptr(), pool.buf.numel()
+        addr = torch.arange(n, dtype=torch.int64)
+        parts = []
+        for name, prm in bb.named_parameters():
+            t = g.get(name) if prm.requires_grad else None
+            if t is None:
+                parts.append(torch.zeros(prm.numel(), dtype=torch.int64))      # element 0 of the pool: never written
+                continue
+            off = (t.data_ptr() - base) // 4
+            inside = 0 <= off and t.numel() == prm.numel() and tuple(t.shape) == tuple(prm.shape) and \
+                off + sum((d - 1) * st for d, st in zip(t.shape, t.stride())) < n
+            if not inside:                                                     # (pool overflow, a narrowed copy): no gather
+                parts = None
+                break
+            parts.append(addr.as_strided(tuple(t.shape), tuple(t.stride()), off).reshape(-1))
+        idx = torch.cat(parts).to(pool.buf.device) if parts is not None else False
+        cache[key] = idx
+    if idx is False:
+        return torch.cat([(g[k] if (k in g and g[k] is not None and prm.requires_grad) else
+                           torch.zeros_like(prm)).reshape(-1) for k, prm in bb.named_parameters()])
+    return pool.buf.index_select(0, idx)
+
+
 class _BackboneFn(torch.autograd.Function):
     """logits = CNNModel(seq, sigma).  sigma has one element per batch row, or ONE element shared by
     the whole batch (the sampler's case: all rows sit at the same time, :527-528)."""
 
     @staticmethod
-    def forward(ctx, bb, seq, sigma, *params):
+    def forward(ctx, bb, seq, sigma, flat_mode, *params):
+        ctx.flat_mode = bool(flat_mode)
         pk = bb.packed()
         # train_dtype 'bf16x3': the convolutions (forward and input gradient) at fp32 grade on the bf16 matrix cores
         # (drk_conv_fwd_x3); weight gradients and everything else stay on the exact-fp32 kernels
@@ -89,8 +133,9 @@ class _BackboneFn(torch.autograd.Function):
         nb = ctx.sigma.shape[0]
         dlogits = dlogits.contiguous()
         g = {}
-        want_w = any(ctx.needs_input_grad[3:])     # a frozen model (the KL reference model) only passes the input gradient on
-        zeros = _ZeroPool((n * 9 * C * C if want_w else 0) + n * nb * C + (n + 2) * C * C + 16 * V * C + (6 * n + 16 + nb) * C, dlogits)
+        want_w = any(ctx.needs_input_grad[4:])     # a frozen model (the KL reference model) only passes the input gradient on
+        zeros = _ZeroPool((n * 9 * C * C if want_w else 0) + n * nb * C + (n + 2) * C * C + 16 * V * C + (6 * n + 16 + nb) * C + 4, dlogits)
+        zeros(4)                                   # element 0: the all-zero slot of _flat_grad
         # head
         dy = torch.empty_like(y)
         dw2, db2 = zeros(V, C), zeros(V)
@@ -154,9 +199,13 @@ class _BackboneFn(torch.autograd.Function):
         for i in range(n):
             g[f'time_layers.{i}.dense.weight'], g[f'time_layers.{i}.dense.bias'] = d_dense_w[i], d_dense_b[i]
         # (a model narrower than the kernels' 128 lanes: its gradients are the leading slices of the padded ones)
-        grads = [bb.narrow(k, g.get(k)) if ctx.needs_input_grad[3 + j] else None for j, k in enumerate(ctx.names)]
         ctx.feats = ctx.masks = ctx.means = ctx.rstds = ctx.y = None
-        return (None, dseq if ctx.needs_input_grad[1] else None, None, *grads)
+        if ctx.flat_mode:
+            g = {k: bb.narrow(k, v) for k, v in g.items()}
+            return (None, dseq if ctx.needs_input_grad[1] else None, None, None,
+                    _flat_grad(ctx, 'f32', g, zeros, want_w, nb) if want_w else None)
+        grads = [bb.narrow(k, g.get(k)) if ctx.needs_input_grad[4 + j] else None for j, k in enumerate(ctx.names)]
+        return (None, dseq if ctx.needs_input_grad[1] else None, None, None, *grads)
 
 
 class _BackboneBf16Fn(torch.autograd.Function):
@@ -167,7 +216,8 @@ class _BackboneBf16Fn(torch.autograd.Function):
     uint8 ReLU masks."""
 
     @staticmethod
-    def forward(ctx, bb, seq, sigma, *params):
+    def forward(ctx, bb, seq, sigma, flat_mode, *params):
+        ctx.flat_mode = bool(flat_mode)
         from . import fastpath
         pk, st = bb.packed(), fastpath._packed(bb)
         vec, wstream = st['vecs'], st['wstream']
@@ -220,9 +270,10 @@ class _BackboneBf16Fn(torch.autograd.Function):
         nb = ctx.sigma.shape[0]
         dlogits = dlogits.contiguous()
         g = {}
-        want_w = any(ctx.needs_input_grad[3:])
+        want_w = any(ctx.needs_input_grad[4:])
         wT = fastpath._packed_T(bb)
-        zeros = _ZeroPool((n * 9 * C * C if want_w else 0) + n * nb * C + (n + 2) * C * C + 16 * V * C + (6 * n + 16 + nb) * C, dlogits)
+        zeros = _ZeroPool((n * 9 * C * C if want_w else 0) + n * nb * C + (n + 2) * C * C + 16 * V * C + (6 * n + 16 + nb) * C + 4, dlogits)
+        zeros(4)                                   # element 0: the all-zero slot of _flat_grad
         # head: exact-fp32 128 -> 5 backward, then final_conv.0 on the bf16 kernels
         dy = torch.empty_like(y)
         dw2, db2 = zeros(V, C), zeros(V)
@@ -277,18 +328,24 @@ class _BackboneBf16Fn(torch.autograd.Function):
         g['time_embedder.1.weight'], g['time_embedder.1.bias'] = d_lin_w, d_lin_b
         for i in range(n):
             g[f'time_layers.{i}.dense.weight'], g[f'time_layers.{i}.dense.bias'] = d_dense_w[i], d_dense_b[i]
-        grads = [g.get(k) if ctx.needs_input_grad[3 + j] else None for j, k in enumerate(ctx.names)]
         ctx.feats = ctx.hs = ctx.masks = ctx.means = ctx.rstds = ctx.y = None
-        return (None, dseq if ctx.needs_input_grad[1] else None, None, *grads)
+        if ctx.flat_mode:
+            return (None, dseq if ctx.needs_input_grad[1] else None, None, None,
+                    _flat_grad(ctx, 'bf16', g, zeros, want_w, nb) if want_w else None)
+        grads = [g.get(k) if ctx.needs_input_grad[4 + j] else None for j, k in enumerate(ctx.names)]
+        return (None, dseq if ctx.needs_input_grad[1] else None, None, None, *grads)
 
 
-def backbone_with_grad(bb, seq, sigma, dtype='fp32'):
+def backbone_with_grad(bb, seq, sigma, dtype='fp32', flat=None):
     """dtype 'bf16': the bf16-MFMA layer kernels (gradients within the bf16 bar); 'fp32': the exact-fp32 kernels;
-    'bf16x3': those with the convolutions at fp32 grade on the bf16 matrix cores (read from bb.train_dtype)."""
+    'bf16x3': those with the convolutions at fp32 grade on the bf16 matrix cores (read from bb.train_dtype).
+    flat: flat_params(bb), built once by a caller that runs many forwards per backward pass (see there)."""
     if dtype is True:
         dtype = 'bf16'
     fn = _BackboneBf16Fn if dtype == 'bf16' else _BackboneFn
-    return fn.apply(bb, seq, sigma, *bb.parameters())
+    if flat is not None:
+        return fn.apply(bb, seq, sigma, True, flat)
+    return fn.apply(bb, seq, sigma, False, *bb.parameters())
 
 
 class _SubsFn(torch.autograd.Function):

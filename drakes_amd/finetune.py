@@ -69,6 +69,7 @@ def sample_finetune_gradient(model, num_steps=None, eps=1e-5, eval_sp_size=None,
     # fine-tune loop's KL term evaluates the same model on the same tensor (finetune_loop.kl_of_step)
     model._soft_logits_cache = {}
     shared = None
+    flat = None                                 # the parameters as one vector: one gradient per soft step, not 129
     n_hard = max(num_steps - trunc, 0)
     first = 0
     if model.hip_dtype == 'bf16' and n_hard > 0 and L <= 224:
@@ -103,7 +104,9 @@ def sample_finetune_gradient(model, num_steps=None, eps=1e-5, eval_sp_size=None,
             if x.ndim == 2:
                 x = F.one_hot(x, num_classes=model.vocab_size).to(torch.float32)
             sig = torch.full((1,), sigma_t if model.time_conditioning else 0.0, dtype=torch.float32, device=dev)
-            logits = autograd.backbone_with_grad(bb, x, sig, bb.train_dtype)
+            if flat is None and torch.is_grad_enabled() and getattr(model, 'hip_flat_grads', True):
+                flat = autograd.flat_params(bb)
+            logits = autograd.backbone_with_grad(bb, x, sig, bb.train_dtype, flat=flat if torch.is_grad_enabled() else None)
             last_x = x
             model._soft_logits_cache[id(x)] = (x, logits, bb._weights_key())
             x, copy_flag = autograd.soft_step_with_grad(logits, x, mc_t, mc_s, temp, copy_flag_temp, seed, i,

@@ -220,3 +220,27 @@ def test_sample_finetune_gradient_bf16_hard_phase(dev, det_sd):
     assert mism < 0.05
     (out.sum(-1) * torch.randn(B, 200, device=dev)).sum().backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters() if p.requires_grad)
+
+
+@pytest.mark.parametrize('soft', ['fp32', 'bf16'])
+def test_flat_parameter_gradients_equal_per_parameter_ones(dev, det_sd, soft):
+    """_sample_finetune_gradient hands every soft step ONE flat parameter vector (autograd.flat_params) so that a backward
+    call returns one gradient instead of 129; model.hip_flat_grads = False keeps the per-parameter form.  Same numbers
+    (up to the order of fp32 atomics), same set of parameters with a gradient, existing .grad accumulated into."""
+    grads = {}
+    for flat in (False, True):
+        m = drakes_amd.Diffusion(drakes_amd.default_config(steps=12, truncate_steps=5)).to(dev)
+        m.load_state_dict(det_sd)
+        m.train()
+        m.hip_soft_dtype = soft
+        m.hip_flat_grads = flat
+        rw = torch.randn(4, 200, generator=torch.Generator().manual_seed(3)).to(dev)
+        for _ in range(2):                                                # two passes: the second accumulates into .grad
+            out = m._sample_finetune_gradient(eval_sp_size=3, seed=11)[0]
+            (out.permute(0, 2, 1) * rw).sum().backward()
+        grads[flat] = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+    assert grads[False].keys() == grads[True].keys() and len(grads[True]) >= 128
+    for k in grads[True]:
+        a, b = grads[False][k], grads[True][k]
+        assert a.shape == b.shape
+        assert float((a - b).abs().max()) <= 1e-5 * max(float(a.abs().max()), 1e-3), k

@@ -97,3 +97,30 @@ def test_narrow_model_refuses_bf16_path(dev):
     m.hip_dtype = 'bf16'
     with pytest.raises(NotImplementedError):
         m._sample(eval_sp_size=2, seed=1)
+
+
+def test_narrow_bf16x3_tokens_equal_exact_path(dev):
+    """hip_dtype = 'bf16x3' (fp32-grade convolutions on the bf16 matrix cores) takes the same zero-padded weights."""
+    m, sd = _model(dev, 32, steps=24)
+    want = m._sample(eval_sp_size=6, seed=11)
+    m.hip_dtype = 'bf16x3'
+    assert torch.equal(m._sample(eval_sp_size=6, seed=11), want)
+
+
+def test_narrow_finetune_gradients_flat_and_per_parameter(dev):
+    """The flat parameter-gradient vector of _sample_finetune_gradient on a narrow model (its gradients are slices of the
+    padded ones, gathered per call) against the per-parameter form."""
+    grads = {}
+    for flat in (False, True):
+        m, _ = _model(dev, 32, steps=10, truncate_steps=4)
+        m.train()
+        m.hip_flat_grads = flat
+        rw = torch.randn(4, 200, generator=torch.Generator().manual_seed(5)).to(dev)
+        out = m._sample_finetune_gradient(eval_sp_size=3, seed=7)[0]
+        (out.permute(0, 2, 1) * rw).sum().backward()
+        grads[flat] = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+    assert grads[False].keys() == grads[True].keys()
+    for k, a in grads[False].items():
+        b = grads[True][k]
+        assert a.shape == b.shape == dict(m.named_parameters())[k].shape
+        assert float((a - b).abs().max()) <= 1e-5 * max(float(a.abs().max()), 1e-3), k
