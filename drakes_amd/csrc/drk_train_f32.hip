@@ -49,7 +49,16 @@ __global__ void __launch_bounds__(256) k_colsum128(const float* __restrict__ x, 
   const long seg = blockIdx.y;
   const long r0 = (long)blockIdx.x * 64;
   float s = 0.f;
-  for (long r = r0 + ph; r < r0 + 64 && r < seg_rows; r += 2) s += x[(seg * seg_rows + r) * DRK_C + c];
+  for (long rb = r0 + ph; rb < r0 + 64; rb += 16) {      // 8 rows in flight per thread (row by row: one round trip each)
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const long r = rb + 2 * j;
+      v[j] = r < seg_rows ? x[(seg * seg_rows + r) * DRK_C + c] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += v[j];
+  }
   if (ph == 1) red[c] = s;
   __syncthreads();
   if (ph == 0) atomicAdd(out + seg * DRK_C + c, s + red[c]);
@@ -271,19 +280,30 @@ __global__ void __launch_bounds__(256) k_head_out_bwd(const float* __restrict__ 
   __syncthreads();
   const int c = threadIdx.x & 127, ph = threadIdx.x >> 7;
   float aw[DRK_V] = {0.f, 0.f, 0.f, 0.f, 0.f}, ab[DRK_V] = {0.f, 0.f, 0.f, 0.f, 0.f};
-  for (long row = (long)blockIdx.x * 64 + ph; row < (long)blockIdx.x * 64 + 64 && row < M; row += 2) {
-    float dl[DRK_V];
+  for (long rb = (long)blockIdx.x * 64 + ph; rb < (long)blockIdx.x * 64 + 64; rb += 16) {
+    // 8 rows per thread in flight (row by row the 32 dependent round trips of a thread were the whole 73 us)
+    float dl[8][DRK_V], yy[8];
 #pragma unroll
-    for (int v = 0; v < DRK_V; ++v) dl[v] = dlogits[row * DRK_V + v];
-    const float yy = y[row * DRK_C + c];
-    float o = 0.f;
+    for (int j = 0; j < 8; ++j) {
+      const long row = rb + 2 * j;
+      const long r = row < M ? row : M - 1;
 #pragma unroll
-    for (int v = 0; v < DRK_V; ++v) {
-      o += dl[v] * ws[v * DRK_C + c];
-      aw[v] += dl[v] * yy;
-      ab[v] += dl[v];
+      for (int v = 0; v < DRK_V; ++v) dl[j][v] = dlogits[r * DRK_V + v];
+      yy[j] = y[r * DRK_C + c];
     }
-    dy[row * DRK_C + c] = o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const long row = rb + 2 * j;
+      if (row >= M) continue;
+      float o = 0.f;
+#pragma unroll
+      for (int v = 0; v < DRK_V; ++v) {
+        o += dl[j][v] * ws[v * DRK_C + c];
+        aw[v] += dl[j][v] * yy[j];
+        ab[v] += dl[j][v];
+      }
+      dy[row * DRK_C + c] = o;
+    }
   }
 #pragma unroll
   for (int v = 0; v < DRK_V; ++v) pw[ph][v][c] = aw[v];
@@ -320,17 +340,27 @@ __global__ void __launch_bounds__(256) k_stem_wgrad(const float* __restrict__ dp
   float acc[DRK_TAPS * DRK_V];
 #pragma unroll
   for (int k = 0; k < DRK_TAPS * DRK_V; ++k) acc[k] = 0.f;
-  for (int rr = ph; rr < 64; rr += 2) {
-    const long row = r0 + rr;
-    if (row >= M) break;
-    const int p = (int)(row % L);
-    const float d = dpre[row * DRK_C + co];
+  for (int rb = ph; rb < 64; rb += 16) {                 // 8 rows of dpre in flight per thread
+    float dv[8];
 #pragma unroll
-    for (int t = 0; t < DRK_TAPS; ++t) {
-      const int pp = p + t - 4;
-      if (pp >= 0 && pp < L) {
+    for (int j = 0; j < 8; ++j) {
+      const long row = r0 + rb + 2 * j;
+      dv[j] = row < M ? dpre[row * DRK_C + co] : 0.f;
+    }
 #pragma unroll
-        for (int v = 0; v < DRK_V; ++v) acc[t * DRK_V + v] += d * xs[(rr + t) * DRK_V + v];
+    for (int j = 0; j < 8; ++j) {
+      const int rr = rb + 2 * j;
+      const long row = r0 + rr;
+      if (row >= M) break;
+      const int p = (int)(row % L);
+      const float d = dv[j];
+#pragma unroll
+      for (int t = 0; t < DRK_TAPS; ++t) {
+        const int pp = p + t - 4;
+        if (pp >= 0 && pp < L) {
+#pragma unroll
+          for (int v = 0; v < DRK_V; ++v) acc[t * DRK_V + v] += d * xs[(rr + t) * DRK_V + v];
+        }
       }
     }
   }
