@@ -55,7 +55,7 @@ def _flat_grad(ctx, cls, g, pool, want_w, nb):
     The pool's layout is the same on every call of one configuration, so the index vector is built once."""
     bb = ctx.bb
     cache = bb.__dict__.setdefault('_flat_idx', {})
-    key = (cls, bool(want_w), int(nb), pool.buf.numel())
+    key = (cls, bool(want_w), int(nb), pool.buf.numel(), tuple(p.requires_grad for p in bb.parameters()))
     idx = cache.get(key)
     if idx is None:
         base, n = pool.buf.data_ptr(), pool.buf.numel()
