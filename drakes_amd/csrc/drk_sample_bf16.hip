@@ -400,7 +400,7 @@ template <int NT, bool ASSIGN, bool FAST>
 __device__ __forceinline__ void epilogue_ln(char* smem, f32x4 (&feat)[NT][2], const f32x4 (&acc)[NT][2], const float* blk,
                                             const float* tbv_src, bool do_ln, int L, int lane, int ct, int grp
 #ifdef DRK_STAMPS
-                                            , unsigned long long (&tacc)[6], unsigned long long& t0
+                                            , unsigned long long (&tacc)[8], unsigned long long& t0
 #endif
                                             ) {
 #pragma clang fp contract(fast)
@@ -548,7 +548,7 @@ __device__ __forceinline__ void sample_body(const SampleArgs& a, char* smem, int
     ring[f] = *(const bf16v8*)(wlane + (long)first_tap * TAP_BYTES + (f >> 1) * KSTEP_BYTES + (f & 1) * SUB_BYTES);
 
 #ifdef DRK_STAMPS
-  unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, t0;
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0;
   STAMP(t0);
   const unsigned long long clk0 = t0, rt0 = __builtin_amdgcn_s_memrealtime();   // shader cycles vs the 100 MHz counter
 #endif
@@ -601,6 +601,7 @@ __device__ __forceinline__ void sample_body(const SampleArgs& a, char* smem, int
         acc[t][1] = s1;
       }
     }
+    ACCUM(7, t0);     // time-bias copy + stem MFMAs
 #ifdef DRK_STAMPS
     epilogue_ln<NT, true, FAST>(smem, feat, acc, vecs, tbl, true, L, lane, ct, grp, tacc, t0);
 #else
@@ -765,6 +766,7 @@ __device__ __forceinline__ void sample_body(const SampleArgs& a, char* smem, int
     }
     __syncthreads();
 
+    ACCUM(5, t0);     // head: final_conv.0 + ReLU + 128 -> 5, four barriers
     // ---- reverse step on this sequence's positions ------------------------------------------
     if (tid < L) {
       const int p = tid;
@@ -799,7 +801,7 @@ __device__ __forceinline__ void sample_body(const SampleArgs& a, char* smem, int
         tok[p] = best;
       }
     }
-    ACCUM(3, t0);
+    ACCUM(6, t0);     // reverse step
   }
   __syncthreads();
 #ifdef DRK_STAMPS
@@ -808,6 +810,9 @@ __device__ __forceinline__ void sample_body(const SampleArgs& a, char* smem, int
     o[0] = tacc[0]; o[1] = __builtin_amdgcn_s_memtime() - clk0; o[2] = tacc[2]; o[3] = tacc[3];
     ((unsigned long long*)a.dbg_feat)[(long)a.B * 33 + b * 8 + wave] = tacc[1];   // wait at the epilogue's first barrier
     ((unsigned long long*)a.dbg_feat)[(long)a.B * 41 + b * 8 + wave] = tacc[4];   // epilogue pass 1
+    ((unsigned long long*)a.dbg_feat)[(long)a.B * 49 + b * 8 + wave] = tacc[5];   // head
+    ((unsigned long long*)a.dbg_feat)[(long)a.B * 57 + b * 8 + wave] = tacc[6];   // reverse step
+    ((unsigned long long*)a.dbg_feat)[(long)a.B * 65 + b * 8 + wave] = tacc[7];   // time-bias copy + stem MFMAs
     tacc[1] = __builtin_amdgcn_s_memrealtime() - rt0;
     if (wave == 0) ((unsigned long long*)a.dbg_feat)[(long)a.B * 32 + b] = tacc[1];   // 100 MHz ticks of this workgroup
   }

@@ -57,6 +57,10 @@ def stamps(B=1024, steps=8):
     ticks = raw[B * 32: B * 32 + B].cpu().numpy().astype(np.float64)          # 100 MHz
     p1 = raw[B * 33: B * 33 + B * 8].reshape(B, 8).cpu().numpy().astype(np.float64)
     p1c = raw[B * 41: B * 41 + B * 8].reshape(B, 8).cpu().numpy().astype(np.float64)
+    head, step, stem = (raw[B * o: B * o + B * 8].reshape(B, 8).cpu().numpy().astype(np.float64) for o in (49, 57, 65))
+    print('per forward, cycles by wave: head', (head.mean(0) / (steps + 1)).round(0), ' reverse step', (step.mean(0) / (steps + 1)).round(0),
+          ' time-bias copy + stem MFMAs', (stem.mean(0) / (steps + 1)).round(0), ' stem epilogue', (st[:, :, 3].mean(0) / (steps + 1)).round(0))
+    st[:, :, 3] += head + step + stem
     cyc = st[:, 0, 1].copy()                                                   # shader cycles of wave 0 over the same span
     print(f'in-kernel clock: {np.median(cyc / ticks) * 0.1:.3f} GHz (median over workgroups; min {np.min(cyc / ticks) * 0.1:.3f}, max {np.max(cyc / ticks) * 0.1:.3f})')
     st[:, :, 1] = p1
