@@ -244,3 +244,42 @@ def test_flat_parameter_gradients_equal_per_parameter_ones(dev, det_sd, soft):
         a, b = grads[False][k], grads[True][k]
         assert a.shape == b.shape
         assert float((a - b).abs().max()) <= 1e-5 * max(float(a.abs().max()), 1e-3), k
+
+
+@pytest.mark.parametrize('B,L,width', [(1, 1, 128), (1, 63, 128), (1, 65, 128), (3, 200, 128), (5, 333, 128), (2, 77, 32)])
+def test_ln_bwd_kernel_vs_float64_autograd(dev, B, L, width):
+    """drk_ln_bwd alone (LayerNorm backward + residual add + column sums, and the fused hand-over to the layer below),
+    against torch autograd in float64 on the same inputs: ragged row counts across its 64-row passes and workgroups, a
+    narrow model's statistics width.  Reference: F.layer_norm in models/dnaconv.py:94.  Bar: 2e-5 of each tensor's max
+    (fp32 sums in another order)."""
+    from drakes_amd import ops
+    g = torch.Generator().manual_seed(B * 1000 + L)
+    r = lambda *s: torch.randn(*s, generator=g)
+    feat, dh, gres = r(B, L, 128), r(B, L, 128), r(B, L, 128)
+    tb, gamma = r(128), 1 + 0.1 * r(128)
+    if width < 128:
+        feat[..., width:] = 0; tb[width:] = 0; gamma[width:] = 0; dh[..., width:] = 0
+    mask = (torch.rand(B, L, 128, generator=g) > 0.4).to(torch.uint8)
+    x = (feat.double() + tb.double()).requires_grad_()
+    gm = gamma.double().requires_grad_()
+    h = F.layer_norm(x[..., :width], (width,), gm[:width], None, 1e-5)
+    (h * dh.double()[..., :width]).sum().backward()
+    dx_ref = torch.zeros(B, L, 128, dtype=torch.float64); dx_ref[..., :width] = x.grad[..., :width]
+    dgam_ref = gm.grad
+    dbet_ref = dh.double().sum((0, 1))
+    o_ref = dx_ref + gres.double()
+    xin = (feat + tb)[..., :width]
+    mean = xin.mean(-1).reshape(-1)
+    rstd = (xin.var(-1, unbiased=False) + 1e-5).rsqrt().reshape(-1)
+    D = lambda t: t.to(dev).contiguous()
+    dxin, dfeat = torch.empty(B, L, 128, device=dev), torch.empty(B, L, 128, device=dev)
+    dgam, dbet, dtb, dbn = (torch.zeros(128, device=dev) for _ in range(4))
+    dc = torch.empty(B, L, 128, dtype=torch.bfloat16, device=dev)
+    ops.ln_bwd(D(dh), D(feat), D(tb), 0, D(gamma), D(mean), D(rstd), D(gres), dxin, dfeat, dgam, dbet, dtb,
+               next_mask=D(mask), dc_next=dc, dbias_next=dbn, width=width)
+    bar = lambda got, ref: (got.double().cpu() - ref).abs().max().item() <= 2e-5 * max(ref.abs().max().item(), 1e-3)
+    assert bar(dxin, dx_ref) and bar(dfeat, o_ref)
+    assert bar(dgam, dgam_ref) and bar(dbet, dbet_ref) and bar(dtb, dx_ref.sum((0, 1)))
+    gated = o_ref * mask.double()
+    assert bar(dbn, gated.sum((0, 1)))
+    assert (dc.float().cpu().double() - gated).abs().max().item() <= 2 ** -8 * max(gated.abs().max().item(), 1e-3)
