@@ -86,11 +86,18 @@ __global__ void __launch_bounds__(256, WGS) k_layer_bf16(const LayerArgs a) {
   const int srow = tid >> 4, scol = tid & 15;
   f32x4 stage[8];
 
+  // the accumulators start at the conv bias (this lane's 8 channels): its load rides under the fetch of the rows instead
+  // of a round trip at the head of the epilogue
   f32x4 acc[LT_NT][2];
+  {
+    const int chb = 32 * ct + 4 * g;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 cb0 = a.bias ? *(const f32x4*)(a.bias + chb) : z4, cb1 = a.bias ? *(const f32x4*)(a.bias + chb + 16) : z4;
 #pragma unroll
-  for (int t = 0; t < LT_NT; ++t) {
-    acc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-    acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < LT_NT; ++t) {
+      acc[t][0] = cb0;
+      acc[t][1] = cb1;
+    }
   }
   LT_STAMP(0);
   const int center = a.taps / 2;
@@ -235,7 +242,12 @@ __global__ void __launch_bounds__(256, WGS) k_layer_bf16(const LayerArgs a) {
   {
 #pragma clang fp contract(fast)
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-  const f32x4 cb0 = a.bias ? *(const f32x4*)(a.bias + ch0) : zero4, cb1 = a.bias ? *(const f32x4*)(a.bias + ch0 + 16) : zero4;
+  // a time bias shared by the batch (the sampler's case) is requested here, two barriers before its use
+  const bool tb_shared = a.ln && a.h_out && a.tb_stride == 0;
+  const f32x4 tbs0 = tb_shared ? *(const f32x4*)(a.tbias + ch0) : zero4, tbs1 = tb_shared ? *(const f32x4*)(a.tbias + ch0 + 16) : zero4;
+  const bool aff = a.ln && a.h_out;          // the next LayerNorm's affine: requested here as well
+  const f32x4 g0 = aff ? *(const f32x4*)(a.gamma + ch0) : zero4, g1 = aff ? *(const f32x4*)(a.gamma + ch0 + 16) : zero4;
+  const f32x4 b0 = aff ? *(const f32x4*)(a.beta + ch0) : zero4, b1 = aff ? *(const f32x4*)(a.beta + ch0 + 16) : zero4;
   f32x4 x[LT_NT][2];
   f32x4 late[PRE ? 1 : LT_NT][2];
   if constexpr (!PRE) {   // every residual request before the first use and the first store (feat_out may be feat, so
@@ -254,8 +266,7 @@ __global__ void __launch_bounds__(256, WGS) k_layer_bf16(const LayerArgs a) {
     const bool ok = row < a.M;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      const f32x4 cb = s ? cb1 : cb0;
-      f32x4 r = acc[t][s] + cb;
+      f32x4 r = acc[t][s];
       if (a.relu) {
         if (a.mask_out && ok) {   // this lane's 4 channels of one row: 4 bytes; the 4 lane groups of a row make 16 contiguous bytes
           const unsigned m = (r[0] > 0.f ? 1u : 0u) | (r[1] > 0.f ? 0x100u : 0u) | (r[2] > 0.f ? 0x10000u : 0u) |
@@ -280,10 +291,14 @@ __global__ void __launch_bounds__(256, WGS) k_layer_bf16(const LayerArgs a) {
     for (int t = 0; t < LT_NT; ++t) {
       const long row = r0 + 16 * t + pn;
       const long brow = (row < a.M ? row : a.M - 1) / L;
-      const float* tb = a.tbias + brow * a.tb_stride + ch0;
-      const f32x4 t0 = *(const f32x4*)(tb), t1 = *(const f32x4*)(tb + 16);
-      x[t][0] += t0;
-      x[t][1] += t1;
+      if (tb_shared) {
+        x[t][0] += tbs0;
+        x[t][1] += tbs1;
+      } else {
+        const float* tb = a.tbias + brow * a.tb_stride + ch0;
+        x[t][0] += *(const f32x4*)(tb);
+        x[t][1] += *(const f32x4*)(tb + 16);
+      }
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int s = 0; s < 2; ++s)
@@ -302,8 +317,6 @@ __global__ void __launch_bounds__(256, WGS) k_layer_bf16(const LayerArgs a) {
       const int tile_i = (g & 1) ? t + 1 : t;
       part[(16 * tile_i + pn) * LT_PART_STRIDE + slot] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
     }
-    const f32x4 g0 = *(const f32x4*)(a.gamma + ch0), g1 = *(const f32x4*)(a.gamma + ch0 + 16);
-    const f32x4 b0 = *(const f32x4*)(a.beta + ch0), b1 = *(const f32x4*)(a.beta + ch0 + 16);
     __syncthreads();
     LT_STAMP(4);
 #pragma unroll
