@@ -82,6 +82,44 @@ __global__ void __launch_bounds__(256) k_stem(const int64_t* __restrict__ x, con
   }
 }
 
+// Token input (the sampler's case): the one-hot picks ONE weight column per tap, so a row is nine 16-byte LDS reads
+// and adds per lane instead of 45 multiply-adds — and the same bits: k_stem adds 1.0 * w at the token's column and
+// 0.0 * w (= +-0) at the others, in the same tap order.  64 rows per workgroup, the 23 KB of weights LDS-resident;
+// half-wave = one row (32 lanes x 4 channels), so the stores are whole 512-byte rows.
+#define STEMT_ROWS 64
+__global__ void __launch_bounds__(256) k_stem_tok(const int64_t* __restrict__ x, const float* __restrict__ w_t,
+                                                  const float* __restrict__ bias, float* __restrict__ feat, long M, int L) {
+  __shared__ __attribute__((aligned(16))) float wl[DRK_TAPS * DRK_V * DRK_C];   // [tap][v][co]
+  __shared__ int toks[STEMT_ROWS + 8];
+  const long r0 = (long)blockIdx.x * STEMT_ROWS;
+  for (int i = threadIdx.x; i < DRK_TAPS * DRK_V * DRK_C / 4; i += 256) ((f32x4*)wl)[i] = ((const f32x4*)w_t)[i];
+  if (threadIdx.x < STEMT_ROWS + 8) {
+    const long r = r0 - 4 + threadIdx.x;
+    toks[threadIdx.x] = (r >= 0 && r < M) ? (int)x[r] : -1;
+  }
+  const int cq = threadIdx.x & 31, rs = threadIdx.x >> 5;
+  const f32x4 b4 = *(const f32x4*)(bias + 4 * cq);
+  __syncthreads();
+#pragma unroll 2
+  for (int k = 0; k < STEMT_ROWS / 8; ++k) {
+    const int rr = rs + 8 * k;
+    const long r = r0 + rr;
+    if (r >= M) break;
+    const int p = (int)(r % L);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < DRK_TAPS; ++t) {
+      const int pp = p + t - 4;
+      const int tk = toks[rr + t];
+      if (pp >= 0 && pp < L && (unsigned)tk < (unsigned)DRK_V) acc += *(const f32x4*)(wl + (t * DRK_V + tk) * DRK_C + 4 * cq);
+    }
+    f32x4 o = acc + b4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = fmaxf(o[i], 0.0f);
+    *(f32x4*)(feat + r * DRK_C + 4 * cq) = o;
+  }
+}
+
 // ------------------------------------------------------------------------------------ LayerNorm (+ time bias)
 // 32 lanes per row (one float4 each), 8 rows per 256-thread workgroup.
 __global__ void __launch_bounds__(256) k_ln_fwd(const float* __restrict__ feat, const float* __restrict__ tbias,
@@ -384,8 +422,12 @@ extern "C" int drk_stem_fwd(const int64_t* x, const float* x_soft, const float* 
   ARGCHECK((x || x_soft) && w_t && bias && feat && B >= 0 && L > 0, "drk_stem_fwd");
   const long M = (long)B * L;
   if (M == 0) return DRK_OK;
-  hipLaunchKernelGGL(k_stem, dim3((unsigned)((M + STEM_ROWS - 1) / STEM_ROWS)), dim3(256), 0, (hipStream_t)stream, x,
-                     x_soft, w_t, bias, feat, M, L);
+  if (x)
+    hipLaunchKernelGGL(k_stem_tok, dim3((unsigned)((M + STEMT_ROWS - 1) / STEMT_ROWS)), dim3(256), 0, (hipStream_t)stream, x,
+                       w_t, bias, feat, M, L);
+  else
+    hipLaunchKernelGGL(k_stem, dim3((unsigned)((M + STEM_ROWS - 1) / STEM_ROWS)), dim3(256), 0, (hipStream_t)stream, x,
+                       x_soft, w_t, bias, feat, M, L);
   DRK_CHECK_LAUNCH();
   return DRK_OK;
 }

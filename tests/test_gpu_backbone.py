@@ -77,3 +77,21 @@ def test_logits_vs_oracle_ragged_shapes(gpu_model, dev, det_sd, B, L):
         want = O.cnn_forward(det_sd, x, torch.zeros(B)).numpy()
         got = gpu_model.backbone(x.to(dev), torch.zeros(B, device=dev)).cpu().numpy()
     np.testing.assert_allclose(got, want, rtol=RTOL, atol=ATOL)
+
+
+def test_stem_token_kernel_equals_one_hot_kernel_bitwise(dev):
+    """Token input runs k_stem_tok (one weight column per tap picked by the token), soft input k_stem (45 multiply-adds):
+    on a one-hot the two must agree bit for bit — same taps, same order, and 0.0 * w terms change nothing
+    (models/dnaconv.py:80-84: F.one_hot then the 5 -> 128 convolution).  Out-of-range ids contribute nothing."""
+    from drakes_amd import ops
+    g = torch.Generator().manual_seed(0)
+    w = (torch.randn(128, 5, 9, generator=g) * 0.3).to(dev)
+    b = torch.randn(128, generator=g).to(dev)
+    wt = ops.pack_stem_weight(w)
+    for B, L in ((1, 1), (1, 5), (3, 200), (2, 77), (4, 1024), (130, 63)):
+        x = torch.randint(0, 5, (B, L), generator=g).to(dev)
+        assert torch.equal(ops.stem_fwd(x, wt, b), ops.stem_fwd(torch.nn.functional.one_hot(x, 5).float(), wt, b)), (B, L)
+    x = torch.randint(0, 5, (2, 50), generator=g).to(dev)
+    bad = x.clone(); bad[0, 7] = 9; bad[1, 0] = -3
+    soft = torch.nn.functional.one_hot(x, 5).float(); soft[0, 7] = 0; soft[1, 0] = 0
+    assert torch.equal(ops.stem_fwd(bad, wt, b), ops.stem_fwd(soft, wt, b))
