@@ -254,6 +254,17 @@ __global__ void __launch_bounds__(256) k_conv_f32(const float* __restrict__ h, c
     }
   }
   const float bco = bias ? bias[co] : 0.0f;
+  // every residual value is requested before the first store: out may be resid, so a load left inside the store loop
+  // could not be moved above the store before it and each would wait out its own round trip
+  float rv[MT][16];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      long row = r0 + 32 * mt + (i & 3) + 8 * (i >> 2) + 4 * half;
+      row = row < M ? row : M - 1;
+      rv[mt][i] = resid ? resid[row * DRK_C + co] : 0.0f;
+    }
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -263,7 +274,7 @@ __global__ void __launch_bounds__(256) k_conv_f32(const float* __restrict__ h, c
         float v = acc[mt][i] + bco;
         if (relu_mask) relu_mask[row * DRK_C + co] = v > 0.0f ? 1 : 0;   // kept for the backward pass
         if (relu) v = fmaxf(v, 0.0f);
-        if (resid) v += resid[row * DRK_C + co];
+        if (resid) v += rv[mt][i];
         out[row * DRK_C + co] = v;
       }
     }
@@ -340,6 +351,15 @@ __global__ void __launch_bounds__(256) k_conv_f32_lds(const float* __restrict__ 
     }
   }
   const float bco = bias ? bias[co] : 0.0f;
+  float rv[2][16];          // the residual, requested before the first store (see k_conv_f32)
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      long row = r0 + 32 * mt + (i & 3) + 8 * (i >> 2) + 4 * half;
+      row = row < M ? row : M - 1;
+      rv[mt][i] = resid ? resid[row * DRK_C + co] : 0.0f;
+    }
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
@@ -349,7 +369,7 @@ __global__ void __launch_bounds__(256) k_conv_f32_lds(const float* __restrict__ 
         float v = acc[mt][i] + bco;
         if (relu_mask) relu_mask[row * DRK_C + co] = v > 0.0f ? 1 : 0;
         if (relu) v = fmaxf(v, 0.0f);
-        if (resid) v += resid[row * DRK_C + co];
+        if (resid) v += rv[mt][i];
         out[row * DRK_C + co] = v;
       }
     }

@@ -222,6 +222,17 @@ __global__ void __launch_bounds__(512, 2) k_conv_x3(const X3Args a, const int ti
     // ---- the two input-channel halves meet through the buffer that holds no staged rows: kh 0 finishes the first
     // X3_NT/2 row tiles, kh 1 the others -----------------------------------------------------------------------------------
     constexpr int HT = X3_NT / 2;
+    // bias and residual of this wave's output rows: requested now, they arrive under the exchange (out may be resid, so
+    // loads left inside the store loop below would each wait out a round trip)
+    const f32x4 cb0 = a.bias ? *(const f32x4*)(a.bias + ch0) : zero4, cb1 = a.bias ? *(const f32x4*)(a.bias + ch0 + 16) : zero4;
+    f32x4 res[HT][2];
+#pragma unroll
+    for (int t = 0; t < HT; ++t) {
+      long row = r0 + 16 * HT * kh + 16 * t + n;
+      row = row < a.M ? row : a.M - 1;
+      res[t][0] = a.resid ? *(const f32x4*)(a.resid + row * DRK_C + ch0) : zero4;
+      res[t][1] = a.resid ? *(const f32x4*)(a.resid + row * DRK_C + ch0 + 16) : zero4;
+    }
     f32x4 mine[HT][2];
     {
       char* const xbuf = smem + (next_tile ? (buf ^ 1) : buf) * X3_BUF;
@@ -257,7 +268,6 @@ __global__ void __launch_bounds__(512, 2) k_conv_x3(const X3Args a, const int ti
     }
     X3_STAMP(11);
     // ---- epilogue: bias, ReLU (+ mask), residual ---------------------------------------------------------------------
-    const f32x4 cb0 = a.bias ? *(const f32x4*)(a.bias + ch0) : zero4, cb1 = a.bias ? *(const f32x4*)(a.bias + ch0 + 16) : zero4;
 #pragma unroll
     for (int t = 0; t < HT; ++t) {
       const long row = r0 + 16 * HT * kh + 16 * t + n;
@@ -276,7 +286,7 @@ __global__ void __launch_bounds__(512, 2) k_conv_x3(const X3Args a, const int ti
 #pragma unroll
           for (int i = 0; i < 4; ++i) r[i] = fmaxf(r[i], 0.f);
         }
-        if (a.resid) r += *(const f32x4*)(a.resid + row * DRK_C + ch0 + 16 * s);
+        r += res[t][s];
         *(f32x4*)(a.out + row * DRK_C + ch0 + 16 * s) = r;
       }
     }
