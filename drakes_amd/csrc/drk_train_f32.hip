@@ -40,16 +40,20 @@ __global__ void __launch_bounds__(256) k_relu_bwd(const float* __restrict__ g, c
   }
 }
 
+// Rows per workgroup of the kernels below that end in one float atomic per column and workgroup (k_colsum128,
+// k_head_out_bwd; k_stem_wgrad, 45 multiply-adds per row and thread, is faster with 64): atomics on the same few hundred addresses serialise, so fewer, taller workgroups win at
+// fine-tune batch sizes (25 600 rows: 200 workgroups of 128 rows instead of 400 of 64).
+#define CS_ROWS 128
 // ------------------------------------------------------------------------------------ column sums
 // out[seg][c] += sum over the rows of segment seg of x[row][c];  rows = nseg * seg_rows, 128 columns.
-// Workgroup = 256 threads = 2 row-phases x 128 columns over a block of 64 rows of one segment.
+// Workgroup = 256 threads = 2 row-phases x 128 columns over a block of CS_ROWS rows of one segment.
 __global__ void __launch_bounds__(256) k_colsum128(const float* __restrict__ x, float* __restrict__ out, long seg_rows) {
   __shared__ float red[128];
   const int c = threadIdx.x & 127, ph = threadIdx.x >> 7;
   const long seg = blockIdx.y;
-  const long r0 = (long)blockIdx.x * 64;
+  const long r0 = (long)blockIdx.x * CS_ROWS;
   float s = 0.f;
-  for (long rb = r0 + ph; rb < r0 + 64; rb += 16) {      // 8 rows in flight per thread (row by row: one round trip each)
+  for (long rb = r0 + ph; rb < r0 + CS_ROWS; rb += 16) {      // 8 rows in flight per thread (row by row: one round trip each)
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -280,7 +284,7 @@ __global__ void __launch_bounds__(256) k_head_out_bwd(const float* __restrict__ 
   __syncthreads();
   const int c = threadIdx.x & 127, ph = threadIdx.x >> 7;
   float aw[DRK_V] = {0.f, 0.f, 0.f, 0.f, 0.f}, ab[DRK_V] = {0.f, 0.f, 0.f, 0.f, 0.f};
-  for (long rb = (long)blockIdx.x * 64 + ph; rb < (long)blockIdx.x * 64 + 64; rb += 16) {
+  for (long rb = (long)blockIdx.x * CS_ROWS + ph; rb < (long)blockIdx.x * CS_ROWS + CS_ROWS; rb += 16) {
     // 8 rows per thread in flight (row by row the 32 dependent round trips of a thread were the whole 73 us)
     float dl[8][DRK_V], yy[8];
 #pragma unroll
@@ -816,7 +820,7 @@ extern "C" int drk_colsum128(const float* x, float* out, long n_seg, long seg_ro
   ARGCHECK(n_seg >= 0 && seg_rows >= 0 && n_seg < 65536, "drk_colsum128");
   if (n_seg == 0 || seg_rows == 0) return DRK_OK;
   ARGCHECK(x && out, "drk_colsum128");
-  hipLaunchKernelGGL(k_colsum128, dim3((unsigned)((seg_rows + 63) / 64), (unsigned)n_seg), dim3(256), 0,
+  hipLaunchKernelGGL(k_colsum128, dim3((unsigned)((seg_rows + CS_ROWS - 1) / CS_ROWS), (unsigned)n_seg), dim3(256), 0,
                      (hipStream_t)stream, x, out, seg_rows);
   DRK_CHECK_LAUNCH();
   return DRK_OK;
@@ -940,7 +944,7 @@ extern "C" int drk_head_out_bwd(const float* dlogits, const float* y, const floa
   DRK_SHAPE_GUARD("drk_head_out_bwd");
   ARGCHECK(dlogits && y && w && dy && dw && db, "drk_head_out_bwd");
   const long M = (long)B * L;
-  hipLaunchKernelGGL(k_head_out_bwd, dim3((unsigned)((M + 63) / 64)), dim3(256), 0, (hipStream_t)stream, dlogits, y, w,
+  hipLaunchKernelGGL(k_head_out_bwd, dim3((unsigned)((M + CS_ROWS - 1) / CS_ROWS)), dim3(256), 0, (hipStream_t)stream, dlogits, y, w,
                      dy, dw, db, M);
   DRK_CHECK_LAUNCH();
   return DRK_OK;
