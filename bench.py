@@ -240,6 +240,32 @@ def secondary_fp32(model, B=1024, dtype='fp32'):
         model.hip_dtype = 'bf16'
 
 
+def _time_layer_kernel(model, B, Ll, reps=20):
+    import ctypes
+    from drakes_amd import _lib, fastpath, ops
+    bb = model.backbone
+    st = fastpath._packed(bb)
+    dev = next(bb.parameters()).device
+    feat = torch.randn(B, Ll, 128, device=dev)
+    h0 = torch.randn(B, Ll, 128, device=dev).to(torch.bfloat16)
+    h1 = torch.empty_like(h0)
+    tbias = bb.time_bias(torch.zeros(1, device=dev))
+    vec = st['vecs']
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    a = (P(h0), P(feat), P(feat), P(h1), P(st['wstream']), P(vec[3]), P(tbias[0, 1]), 0, P(vec[4]), P(vec[5]), B, Ll, 9, 1, 1, 1,
+         None, None, None, ops._stream())
+    for _ in range(3):
+        _lib.call('drk_layer_bf16', *a)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for s_, e_ in evs:
+        s_.record()
+        _lib.call('drk_layer_bf16', *a)
+        e_.record()
+    torch.cuda.synchronize()
+    ms = sum(s_.elapsed_time(e_) for s_, e_ in evs) / reps
+    return 'k_layer_bf16 (one residual layer, timed alone after the run)', reps, ms, 2.0 * B * Ll * 9 * 128 * 128
+
+
 def workload_long(args, rank, world, dev, barrier):
     """configs[4] per GPU: L=1024, 512 steps, bf16 layer kernels (the fused loop holds L <= 224)."""
     import drakes_amd
@@ -259,6 +285,10 @@ def workload_long(args, rank, world, dev, barrier):
     elapsed = time.perf_counter() - t0
     name, n, ms, fl = ops.PROFILE.disable()
     rows = B * Ll
+    if not n and args.dtype == 'bf16':
+        # the captured step replays without passing the launch brackets: time the dominant kernel (one residual layer,
+        # dilation 1) on its own after the timed region, same shapes, HIP events on its stream
+        name, n, ms, fl = _time_layer_kernel(m, B, Ll)
     roof = {'bound': 'hbm', 'kernel': name, 'launches_timed': n, 'avg_launch_ms': ms}
     if ms and name and 'layer' in name:
         per_row = getattr(ops, 'LAYER_BYTES_PER_ROW', 1536)
