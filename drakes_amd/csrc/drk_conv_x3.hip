@@ -302,10 +302,12 @@ __global__ void __launch_bounds__(512, 2) k_conv_x3(const X3Args a, const int ti
 // NT = 16-row tiles per workgroup tile: 6 (96 rows, as the per-tap kernel) or 8 (128 rows: for launches of few tiles —
 // the fine-tune shapes — where 128-row tiles need one round of the chip and 96-row tiles two).  Image rows: 16 NT + 32.
 #define X3H_HALO_MAX 16
-template <int NT>
+// HM = the largest halo the image has room for: 16 rows (dilation <= 4) with 96- or 128-row tiles, or 64 rows (dilation
+// 16) with 64-row tiles (192 image rows, 150.5 KB).
+template <int NT, int HM = X3H_HALO_MAX>
 __global__ void __launch_bounds__(512, 2) k_conv_x3_halo(const X3Args a, const int tiles_per_wg, const int ntiles) {
   constexpr int TROWS = 16 * NT;                         // rows per tile
-  constexpr int X3H_ROWS = TROWS + 2 * X3H_HALO_MAX;     // image rows
+  constexpr int X3H_ROWS = TROWS + 2 * HM;               // image rows
   constexpr int X3H_ZERO = X3H_ROWS * X3_ROWB;           // the all-zero row
   constexpr int X3H_SMEM = X3H_ZERO + X3_ROWB;           // 101 136 B (NT = 6), 126 224 B (NT = 8)
   constexpr int NST = X3H_ROWS / 16;                     // staging passes of 16 rows
@@ -321,7 +323,7 @@ __global__ void __launch_bounds__(512, 2) k_conv_x3_halo(const X3Args a, const i
   const int L = a.L;
   const int center = a.taps / 2;
   const int last_tap = a.taps - 1 - a.first_tap;
-  const int halo = center * a.dil;                       // <= X3H_HALO_MAX, checked by the entry point
+  const int halo = center * a.dil;                       // <= HM, checked by the entry point
   const int rows_total = TROWS + 2 * halo;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
@@ -531,12 +533,15 @@ extern "C" int drk_conv_fwd_x3(const float* h, const void* w3, const float* bias
   if (a.M >= (1L << 34)) return drk_set_error_msg(DRK_EINVAL, "drk_conv_fwd_x3: too many rows");
   const long t6 = (a.M + 95) / 96, t8 = (a.M + 127) / 128;
   const bool halo_form = center * dilation <= X3H_HALO_MAX;
+  const bool halo64 = !halo_form && center * dilation <= 64;   // dilation 16: 64-row tiles around a 64-row halo
   // 128-row tiles where they take fewer row-rounds of the chip (few tiles: one round of 128 rows instead of two of 96)
   const bool big = halo_form && ((t8 + cus - 1) / cus) * 8 < ((t6 + cus - 1) / cus) * 6;
-  const long ntiles = big ? t8 : t6;
+  const long ntiles = halo64 ? (a.M + 63) / 64 : big ? t8 : t6;
   const int per = (int)((ntiles + cus - 1) / cus);
   const int nwg = (int)((ntiles + per - 1) / per);
-  if (big)
+  if (halo64)
+    hipLaunchKernelGGL((k_conv_x3_halo<4, 64>), dim3(nwg), dim3(512), 0, (hipStream_t)stream, a, per, (int)ntiles);
+  else if (big)
     hipLaunchKernelGGL(k_conv_x3_halo<8>, dim3(nwg), dim3(512), 0, (hipStream_t)stream, a, per, (int)ntiles);
   else if (halo_form)
     hipLaunchKernelGGL(k_conv_x3_halo<6>, dim3(nwg), dim3(512), 0, (hipStream_t)stream, a, per, (int)ntiles);

@@ -17,7 +17,8 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize('B,L,d,taps', [(3, 200, 1, 9), (2, 77, 4, 9), (2, 200, 16, 9), (3, 200, 64, 9), (1, 1024, 64, 9),
                                         (5, 33, 0, 1), (1, 1, 1, 9), (2, 129, 16, 9),
-                                        (128, 200, 4, 9), (131, 200, 1, 9), (129, 199, 0, 1)])   # 128-row tiles (few tiles)
+                                        (128, 200, 4, 9), (131, 200, 1, 9), (129, 199, 0, 1),    # 128-row tiles (few tiles)
+                                        (131, 199, 16, 9), (3, 77, 16, 9), (1, 20, 16, 9), (300, 200, 16, 9)])   # 64-row tiles, 64-row halo
 def test_conv_x3_kernel(dev, B, L, d, taps):
     g = torch.Generator(device='cpu').manual_seed(B * 1000 + L + d)
     w = torch.randn(128, 128, taps, generator=g) * 0.05
