@@ -404,6 +404,68 @@ __global__ void __launch_bounds__(256) k_ln_bf16(const float* __restrict__ feat,
   *(bf16v4*)(h + row * 256 + 8 * lr) = pk;
 }
 
+// Stem (token input) and the first LayerNorm in one launch: k_stem_tok's arithmetic (drk_cnn_f32.hip: one LDS-resident
+// weight column per tap, same bits as drk_stem_fwd) with a half-wave holding a whole row, so k_ln_bf16's statistics run on
+// the row while it is still in registers — feat is written, not read back (268 MB less per forward at 262 144 rows).
+#define SLN_ROWS 64
+__global__ void __launch_bounds__(256) k_stem_ln_bf16(const int64_t* __restrict__ x, const float* __restrict__ w_t,
+                                                      const float* __restrict__ bias, const float* __restrict__ tbias,
+                                                      long tb_stride, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, float* __restrict__ feat,
+                                                      char* __restrict__ h, float* __restrict__ mean_out,
+                                                      float* __restrict__ rstd_out, long M, int L) {
+  __shared__ __attribute__((aligned(16))) float wl[DRK_TAPS * DRK_V * DRK_C];   // [tap][v][co]
+  __shared__ int toks[SLN_ROWS + 8];
+  const long r0 = (long)blockIdx.x * SLN_ROWS;
+  for (int i = threadIdx.x; i < DRK_TAPS * DRK_V * DRK_C / 4; i += 256) ((f32x4*)wl)[i] = ((const f32x4*)w_t)[i];
+  if (threadIdx.x < SLN_ROWS + 8) {
+    const long r = r0 - 4 + threadIdx.x;
+    toks[threadIdx.x] = (r >= 0 && r < M) ? (int)x[r] : -1;
+  }
+  const int lr = threadIdx.x & 31, rs = threadIdx.x >> 5;
+  const f32x4 b4 = *(const f32x4*)(bias + 4 * lr);
+  const f32x4 gm = *(const f32x4*)(gamma + 4 * lr), be = *(const f32x4*)(beta + 4 * lr);
+  __syncthreads();
+#pragma unroll 2
+  for (int k = 0; k < SLN_ROWS / 8; ++k) {
+    const int rr = rs + 8 * k;
+    const long row = r0 + rr;
+    if (row >= M) break;
+    const int p = (int)(row % L);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < DRK_TAPS; ++t) {
+      const int pp = p + t - 4;
+      const int tk = toks[rr + t];
+      if (pp >= 0 && pp < L && (unsigned)tk < (unsigned)DRK_V) acc += *(const f32x4*)(wl + (t * DRK_V + tk) * DRK_C + 4 * lr);
+    }
+    f32x4 v = acc + b4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.0f);
+    *(f32x4*)(feat + row * DRK_C + 4 * lr) = v;
+    // ---- k_ln_bf16 on the row (same operations in the same order)
+    if (tbias) v += *(const f32x4*)(tbias + (row / L) * tb_stride + 4 * lr);
+    float s1 = (v[0] + v[1]) + (v[2] + v[3]);
+    float s2 = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+#pragma unroll
+    for (int o = 16; o >= 1; o >>= 1) {
+      s1 += __shfl_xor(s1, o);
+      s2 += __shfl_xor(s2, o);
+    }
+    const float mean = s1 * (1.0f / 128.0f);
+    const float var = fmaxf(s2 * (1.0f / 128.0f) - mean * mean, 0.0f);
+    const float rstd = __builtin_amdgcn_rsqf(var + 1e-5f);
+    if (mean_out && lr == 0) {
+      mean_out[row] = mean;
+      rstd_out[row] = rstd;
+    }
+    bf16v4 pk;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pk[i] = (__bf16)(((v[i] - mean) * rstd) * gm[i] + be[i]);
+    *(bf16v4*)(h + row * 256 + 8 * lr) = pk;
+  }
+}
+
 #define LARGCHECK(cond, name) \
   if (!(cond)) return drk_set_error_msg(DRK_EINVAL, name ": bad arguments")
 
@@ -445,6 +507,18 @@ extern "C" int drk_ln_fwd_bf16(const float* feat, const float* tbias, long tb_st
   const long M = (long)B * L;
   hipLaunchKernelGGL(k_ln_bf16, dim3((unsigned)((M + 7) / 8)), dim3(256), 0, (hipStream_t)stream, feat, tbias, tb_stride, gamma,
                      beta, (char*)h, mean, rstd, M, L);
+  DRK_CHECK_LAUNCH();
+  return DRK_OK;
+}
+
+extern "C" int drk_stem_ln_bf16(const int64_t* x, const float* w_t, const float* bias, const float* tbias, long tb_stride,
+                                const float* gamma, const float* beta, float* feat, void* h, float* mean, float* rstd, int B,
+                                int L, void* stream) {
+  DRK_SHAPE_GUARD("drk_stem_ln_bf16");
+  LARGCHECK(x && w_t && bias && gamma && beta && feat && h && (!mean == !rstd), "drk_stem_ln_bf16");
+  const long M = (long)B * L;
+  hipLaunchKernelGGL(k_stem_ln_bf16, dim3((unsigned)((M + SLN_ROWS - 1) / SLN_ROWS)), dim3(256), 0, (hipStream_t)stream, x, w_t,
+                     bias, tbias, tb_stride, gamma, beta, feat, (char*)h, mean, rstd, M, L);
   DRK_CHECK_LAUNCH();
   return DRK_OK;
 }

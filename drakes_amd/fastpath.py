@@ -256,12 +256,16 @@ def forward_bf16_layers(bb, seq, tbias, tb_stride, work=None):
             t = torch.empty(*shape, dtype=dtype, device=seq.device)
             work[name] = t
         return t
-    feat = ops.stem_fwd(seq, pk['stem_w'], pk['stem_b'], out=buf('feat', torch.float32, B, L, ops.C))
     h = [buf('h0', torch.bfloat16, B, L, ops.C), buf('h1', torch.bfloat16, B, L, ops.C)]
     fp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
     vec = st['vecs']                               # [(n+1)*3, 128]: see pack_stream
-    _lib.call('drk_ln_fwd_bf16', fp(feat), fp(tbias[0, 0]), tb_stride, fp(vec[1]), fp(vec[2]), _bf16_ptr(h[0], 'h'), None, None, B, L,
-              ops._stream())
+    if seq.dtype == torch.int64:                   # tokens: stem and first LayerNorm in one launch
+        feat, _ = ops.stem_ln_bf16(seq, pk['stem_w'], pk['stem_b'], tbias[0, 0], tb_stride, vec[1], vec[2],
+                                   feat=buf('feat', torch.float32, B, L, ops.C), out=h[0])
+    else:
+        feat = ops.stem_fwd(seq, pk['stem_w'], pk['stem_b'], out=buf('feat', torch.float32, B, L, ops.C))
+        _lib.call('drk_ln_fwd_bf16', fp(feat), fp(tbias[0, 0]), tb_stride, fp(vec[1]), fp(vec[2]), _bf16_ptr(h[0], 'h'), None, None,
+                  B, L, ops._stream())
     flop = 2.0 * B * L * 9 * ops.C * ops.C
     for i in range(n):
         last = i + 1 == n

@@ -357,6 +357,16 @@ def ln_fwd_bf16(feat, tbias_layer, tb_stride, gamma, beta, out=None, mean=None, 
     return out
 
 
+def stem_ln_bf16(x, w_t, bias, tbias_layer, tb_stride, gamma, beta, feat=None, out=None, mean=None, rstd=None):
+    """stem_fwd on int64 tokens and ln_fwd_bf16 of its output in one launch (drk_stem_ln_bf16): returns (feat, h)."""
+    B, L = x.shape[0], x.shape[1]
+    feat = feat if feat is not None else torch.empty(B, L, C, dtype=torch.float32, device=x.device)
+    out = out if out is not None else torch.empty(B, L, C, dtype=torch.bfloat16, device=x.device)
+    _lib.call('drk_stem_ln_bf16', _i(x, 'x'), _f(w_t, 'w_t'), _f(bias, 'bias'), _raw(tbias_layer), tb_stride, _f(gamma, 'gamma'),
+              _f(beta, 'beta'), _f(feat, 'feat'), _b16(out, 'h'), _f(mean, 'mean'), _f(rstd, 'rstd'), B, L, _stream())
+    return feat, out
+
+
 def layer_bf16(h, wfrag, feat_out, *, feat=None, h_out=None, bias=None, tbias=None, tb_stride=0, gamma=None, beta=None,
                taps=9, dilation=1, relu=True, relu_mask=None, mean=None, rstd=None):
     """One launch of drk_layer_bf16 (see include/drakes_hip.h).  wfrag: a view into the packed fragment stream that

@@ -277,6 +277,13 @@ int drk_layer_bf16(const void* h, const float* feat, float* feat_out, void* h_ou
  * float32 [B*L] outputs for the backward pass. */
 int drk_ln_fwd_bf16(const float* feat, const float* tbias, long tb_stride, const float* gamma, const float* beta, void* h,
                     float* mean, float* rstd, int B, int L, void* stream);
+/* drk_stem_fwd on token input (models/dnaconv.py:80-86: one-hot, Conv1d(5 -> 128, k = 9), ReLU) and drk_ln_fwd_bf16 of
+ * its output (dnaconv.py:92-93) in one launch: feat float32 [B*L][128] and h bf16 [B*L][128] are both written, with the
+ * bits the two calls give; w_t [9][5][128] as for drk_stem_fwd; tbias NULL or one row per batch element (stride
+ * tb_stride floats, 0 = shared); mean, rstd optional float32 [B*L]. */
+int drk_stem_ln_bf16(const int64_t* x, const float* w_t, const float* bias, const float* tbias, long tb_stride,
+                     const float* gamma, const float* beta, float* feat, void* h, float* mean, float* rstd, int B, int L,
+                     void* stream);
 
 /* ---- bf16 backward of the denoiser (the differentiable bf16 path; reference: torch autograd over
  * models/dnaconv.py:88-101 inside _sample_finetune_gradient, diffusion_gosai_update.py:589-630) ----------------------

@@ -396,3 +396,23 @@ def test_bf16_layernorm_with_large_stream_mean(dev, det_sd):
         got = got.cpu().numpy()
         print(f'|mean|/std = {ratio:.1f}: {name} max|kernel-emulation| = {np.abs(got - emu).max():.2e}')
         assert np.abs(got - emu).max() < 6e-2 and np.sqrt(((got - emu) ** 2).mean()) < 1e-2
+
+
+def test_stem_ln_fused_equals_two_launches_bitwise(dev):
+    """drk_stem_ln_bf16 (token stem + first LayerNorm in one launch) against drk_stem_fwd followed by drk_ln_fwd_bf16:
+    feat, h, mean and rstd must be the same bits (models/dnaconv.py:80-93), ragged shapes and per-row time biases included."""
+    g = torch.Generator().manual_seed(1)
+    w = (torch.randn(128, 5, 9, generator=g) * 0.3).to(dev)
+    b, gamma, beta = (torch.randn(128, generator=g).to(dev) for _ in range(3))
+    wt = ops.pack_stem_weight(w)
+    for B, L, per_row in ((1, 1, False), (3, 200, False), (2, 77, True), (4, 1024, False), (130, 63, True)):
+        x = torch.randint(0, 5, (B, L), generator=g).to(dev)
+        tb = torch.randn(B if per_row else 1, 128, generator=g).to(dev)
+        stride = tb.stride(0) if per_row else 0
+        feat = ops.stem_fwd(x, wt, b)
+        m1, r1 = torch.empty(B * L, device=dev), torch.empty(B * L, device=dev)
+        h = ops.ln_fwd_bf16(feat, tb[0], stride, gamma, beta, mean=m1, rstd=r1)
+        m2, r2 = torch.empty(B * L, device=dev), torch.empty(B * L, device=dev)
+        feat2, h2 = ops.stem_ln_bf16(x, wt, b, tb[0], stride, gamma, beta, mean=m2, rstd=r2)
+        assert torch.equal(feat, feat2) and torch.equal(h.view(torch.int16), h2.view(torch.int16)), (B, L)
+        assert torch.equal(m1, m2) and torch.equal(r1, r2), (B, L)
