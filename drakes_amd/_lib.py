@@ -54,6 +54,7 @@ SIGNATURES = {
     'drk_head_out_fwd': [_P, _P, _P, _P, c_int, c_int, _P],
     'drk_layer_bf16': [_P, _P, _P, _P, _P, _P, _P, c_long, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P],
     'drk_ln_fwd_bf16': [_P, _P, c_long, _P, _P, _P, _P, _P, c_int, c_int, _P],
+    'drk_head_bf16': [_P, _P, _P, _P, _P, _P, c_int, c_int, _P],
     'drk_stem_ln_bf16': [_P, _P, _P, _P, c_long, _P, _P, _P, _P, _P, _P, c_int, c_int, _P],
     'drk_gate_bf16': [_P, _P, _P, _P, _P, c_int, c_int, _P, c_long, _P],
     'drk_conv_wgrad_bf16': [_P, _P, _P, c_int, c_int, c_int, c_int, _P, c_long, _P],

@@ -58,6 +58,9 @@ struct LayerArgs {
   const float* beta;
   long M;
   int L, taps, dil, first_tap, ln;
+  const float* head_w;      // drk_head_bf16 only: final_conv.2 [5][128] / [5]; the 128 -> 5 projection of the ReLU output
+  const float* head_b;      //   is taken from the tile while it is on the chip, feat_out is not written
+  float* logits;            //   float32 [M][5]
 };
 
 // LDS: TROWS rows of 272 B (two 128-row tap buffers, or one halo tile), then the LayerNorm partials, whose first 272
@@ -278,11 +281,56 @@ __global__ void __launch_bounds__(256, WGS) k_layer_bf16(const LayerArgs a) {
       }
       if constexpr (PRE) r += res[t][s];
       else r += late[t][s];
-      if (ok) *(f32x4*)(a.feat_out + row * DRK_C + ch0 + 16 * s) = r;
+      if (ok && a.feat_out) *(f32x4*)(a.feat_out + row * DRK_C + ch0 + 16 * s) = r;
       x[t][s] = r;
     }
   }
   LT_STAMP(3);
+  if (a.logits) {   // (wave-uniform) head: y tile -> LDS as fp32 rows, then k_head_out's arithmetic on it, bit for bit
+#pragma clang fp contract(off)
+    __syncthreads();   // every wave is past its reads of the activation tiles
+    float* const stg = (float*)tile0;                       // [128 rows][132 floats]: 67 584 B of the 69 632-byte tile area
+    float* const ws = (float*)(smem + LT_TILE_BYTES);       // [5][128]: the partials' area (6 144 B)
+#pragma unroll
+    for (int t = 0; t < LT_NT; ++t) {
+      *(f32x4*)(stg + (16 * t + pn) * 132 + ch0) = x[t][0];
+      *(f32x4*)(stg + (16 * t + pn) * 132 + ch0 + 16) = x[t][1];
+    }
+    for (int i = tid; i < DRK_V * DRK_C; i += 256) ws[i] = a.head_w[i];
+    __syncthreads();
+    const int s8 = tid & 7;
+#pragma unroll 1
+    for (int pass = 0; pass < LT_ROWS / 32; ++pass) {
+      const int rowl = 32 * pass + (tid >> 3);
+      const long row = r0 + rowl;
+      float part[DRK_V] = {0.f, 0.f, 0.f, 0.f, 0.f};
+      if (row < a.M) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int ch = 4 * (s8 + 8 * c);
+          const f32x4 av = *(const f32x4*)(stg + rowl * 132 + ch);
+#pragma unroll
+          for (int v = 0; v < DRK_V; ++v) {
+            const f32x4 ww = *(const f32x4*)(ws + v * DRK_C + ch);
+            part[v] += (av[0] * ww[0] + av[1] * ww[1]) + (av[2] * ww[2] + av[3] * ww[3]);
+          }
+        }
+      }
+#pragma unroll
+      for (int v = 0; v < DRK_V; ++v) {
+        part[v] += __shfl_xor(part[v], 4);
+        part[v] += __shfl_xor(part[v], 2);
+        part[v] += __shfl_xor(part[v], 1);
+      }
+      if (row < a.M && s8 < DRK_V) {
+        float o = part[0];
+#pragma unroll
+        for (int v = 1; v < DRK_V; ++v) o = (s8 == v) ? part[v] : o;
+        a.logits[row * DRK_V + s8] = o + a.head_b[s8];
+      }
+    }
+    return;
+  }
   if (!a.h_out) return;
   __syncthreads();   // every wave is past its reads of the activation tiles: tile[0] becomes the h' staging area
   if (a.ln) {
@@ -481,6 +529,7 @@ extern "C" int drk_layer_bf16(const void* h, const float* feat, float* feat_out,
   LARGCHECK((const void*)h != (const void*)h_out, "drk_layer_bf16 (h and h_out must be distinct buffers)");
   LayerArgs a;
   a.mask_out = relu_mask; a.mean_out = mean; a.rstd_out = rstd; a.relu = relu ? 1 : 0;
+  a.head_w = nullptr; a.head_b = nullptr; a.logits = nullptr;
   a.h = (const char*)h; a.feat = feat; a.feat_out = feat_out; a.h_out = (char*)h_out; a.wfrag = (const char*)wfrag;
   a.bias = bias; a.tbias = tbias; a.tb_stride = tb_stride; a.gamma = gamma; a.beta = beta;
   a.M = (long)B * L; a.L = L; a.taps = taps; a.dil = dilation; a.ln = ln ? 1 : 0;
@@ -519,6 +568,22 @@ extern "C" int drk_stem_ln_bf16(const int64_t* x, const float* w_t, const float*
   const long M = (long)B * L;
   hipLaunchKernelGGL(k_stem_ln_bf16, dim3((unsigned)((M + SLN_ROWS - 1) / SLN_ROWS)), dim3(256), 0, (hipStream_t)stream, x, w_t,
                      bias, tbias, tb_stride, gamma, beta, feat, (char*)h, mean, rstd, M, L);
+  DRK_CHECK_LAUNCH();
+  return DRK_OK;
+}
+
+extern "C" int drk_head_bf16(const void* h, const void* wfrag, const float* bias, const float* head_w, const float* head_b,
+                             float* logits, int B, int L, void* stream) {
+  DRK_SHAPE_GUARD("drk_head_bf16");
+  LARGCHECK(h && wfrag && head_w && head_b && logits, "drk_head_bf16");
+  LayerArgs a;
+  a.mask_out = nullptr; a.mean_out = nullptr; a.rstd_out = nullptr; a.relu = 1;
+  a.h = (const char*)h; a.feat = nullptr; a.feat_out = nullptr; a.h_out = nullptr; a.wfrag = (const char*)wfrag;
+  a.bias = bias; a.tbias = nullptr; a.tb_stride = 0; a.gamma = nullptr; a.beta = nullptr;
+  a.M = (long)B * L; a.L = L; a.taps = 1; a.dil = 0; a.ln = 0; a.first_tap = 0;
+  a.head_w = head_w; a.head_b = head_b; a.logits = logits;
+  const dim3 grid((unsigned)((a.M + LT_ROWS - 1) / LT_ROWS));
+  hipLaunchKernelGGL((k_layer_bf16<true, 256, 2, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
   DRK_CHECK_LAUNCH();
   return DRK_OK;
 }

@@ -274,7 +274,8 @@ def forward_bf16_layers(bb, seq, tbias, tb_stride, work=None):
                 None if last else fp(tbias[0, i + 1]), tb_stride, None if last else fp(vec[3 * (i + 1) + 1]),
                 None if last else fp(vec[3 * (i + 1) + 2]), B, L, 9, bb.dilation(i), 0 if last else 1, 1, None, None, None, ops._stream())
         ops.PROFILE.bracket('k_layer_bf16', flop, lambda: _lib.call('drk_layer_bf16', *args))
-    y = buf('y', torch.float32, B, L, ops.C)
-    _lib.call('drk_layer_bf16', _bf16_ptr(h[n & 1], 'h'), None, fp(y), None, fp(st['wstream'][9 * n:]), fp(vec[3 * n + 1]),
-              None, 0, None, None, B, L, 1, 0, 0, 1, None, None, None, ops._stream())
-    return ops.head_out_fwd(y, pk['head2_w'], pk['head2_b'], out=buf('logits', torch.float32, B, L, ops.V))
+    # final_conv.0 (1x1) + ReLU + final_conv.2 (128 -> 5) in one launch: the 128-channel intermediate never leaves the chip
+    logits = buf('logits', torch.float32, B, L, ops.V)
+    _lib.call('drk_head_bf16', _bf16_ptr(h[n & 1], 'h'), fp(st['wstream'][9 * n:]), fp(vec[3 * n + 1]), fp(pk['head2_w']),
+              fp(pk['head2_b']), fp(logits), B, L, ops._stream())
+    return logits

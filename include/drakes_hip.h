@@ -284,6 +284,12 @@ int drk_ln_fwd_bf16(const float* feat, const float* tbias, long tb_stride, const
 int drk_stem_ln_bf16(const int64_t* x, const float* w_t, const float* bias, const float* tbias, long tb_stride,
                      const float* gamma, const float* beta, float* feat, void* h, float* mean, float* rstd, int B, int L,
                      void* stream);
+/* The denoiser's head in one launch (models/dnaconv.py:60-63, 103-104: Conv1d(128 -> 128, k = 1), ReLU, Conv1d(128 -> 5,
+ * k = 1)): h = bf16 of the last residual state [B*L][128]; wfrag = final_conv.0 in fragment order (the stream's last tap),
+ * bias [128]; head_w [5][128], head_b [5] float32; logits float32 [B*L][5].  The 128-channel intermediate stays on the
+ * chip; the bits are those of drk_layer_bf16(taps = 1, relu = 1) followed by drk_head_out_fwd. */
+int drk_head_bf16(const void* h, const void* wfrag, const float* bias, const float* head_w, const float* head_b,
+                  float* logits, int B, int L, void* stream);
 
 /* ---- bf16 backward of the denoiser (the differentiable bf16 path; reference: torch autograd over
  * models/dnaconv.py:88-101 inside _sample_finetune_gradient, diffusion_gosai_update.py:589-630) ----------------------

@@ -416,3 +416,27 @@ def test_stem_ln_fused_equals_two_launches_bitwise(dev):
         feat2, h2 = ops.stem_ln_bf16(x, wt, b, tb[0], stride, gamma, beta, mean=m2, rstd=r2)
         assert torch.equal(feat, feat2) and torch.equal(h.view(torch.int16), h2.view(torch.int16)), (B, L)
         assert torch.equal(m1, m2) and torch.equal(r1, r2), (B, L)
+
+
+def test_head_fused_equals_two_launches_bitwise(dev):
+    """drk_head_bf16 (final_conv.0 + ReLU + final_conv.2 in one launch, the 128-channel intermediate kept on the chip)
+    against drk_layer_bf16(taps = 1) followed by drk_head_out_fwd: the same logits bit for bit (models/dnaconv.py:103-104)."""
+    import ctypes
+    from drakes_amd import _lib
+    torch.manual_seed(0)
+    m = drakes_amd.Diffusion(drakes_amd.default_config()).to(dev).eval()
+    bb = m.backbone
+    with torch.no_grad():
+        bb.final_conv[2].bias.add_(torch.randn(5, device=dev))
+    st, pk = fastpath._packed(bb), bb.packed()
+    n = bb.num_layers
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    for B, L in ((1, 1), (3, 200), (2, 77), (3, 1024), (131, 63)):
+        h = torch.randn(B, L, 128, device=dev).to(torch.bfloat16)
+        y = ops.layer_bf16(h, st['wstream'][9 * n:], torch.empty(B, L, 128, device=dev), bias=st['vecs'][3 * n + 1], taps=1,
+                           dilation=0, relu=True)
+        want = ops.head_out_fwd(y, pk['head2_w'], pk['head2_b'])
+        got = torch.full((B, L, 5), float('nan'), device=dev)
+        _lib.call('drk_head_bf16', P(h), P(st['wstream'][9 * n:]), P(st['vecs'][3 * n + 1]), P(pk['head2_w']), P(pk['head2_b']),
+                  P(got), B, L, ops._stream())
+        assert torch.equal(got, want), (B, L, float((got - want).abs().max()))
