@@ -5,6 +5,7 @@
 // The 128->128 k=9 dilated convolution is an implicit GEMM (M = B*L positions, N = 128,
 // K = 9*128) on the f32-input MFMA v_mfma_f32_32x32x2_f32: bit-for-bit an fp32 fma chain, at
 // the fp32 vector peak (155 TF), with one VGPR per operand per lane.
+#include <type_traits>
 #include "drk_common.h"
 #include "../../include/drakes_hip.h"
 
@@ -311,32 +312,45 @@ __global__ void __launch_bounds__(256) k_conv_f32_lds(const float* __restrict__ 
   for (int i = 0; i < 8; ++i) spos[i] = (int)((r0 + srow + 8 * i) % L);
   const int center = taps / 2;
   f32x4 stage[8];
+  unsigned live = 0;
+  // Unconditional loads from in-range rows, blanked when parked: the number of loads in flight is then static, and the
+  // compiler's waits for the weight fragments do not also wait for the rows requested after them.
   auto fetch = [&](int t) {
     const int off = (t - center) * dil;
+    live = 0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const long row = r0 + srow + 8 * i;
       const int p = spos[i] + off;
-      stage[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (row < M && p >= 0 && p < L) stage[i] = *(const f32x4*)(h + (row + off) * DRK_C + 4 * scol);
+      const bool ok = row < M && p >= 0 && p < L;
+      live |= ok ? (1u << i) : 0u;
+      const long src = ok ? row + off : r0;            // a dead row re-reads the tile's first row: a cache hit
+      stage[i] = *(const f32x4*)(h + src * DRK_C + 4 * scol);
     }
   };
   auto park = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) *(f32x4*)(&tile[buf][(srow + 8 * i) * CL_STRIDE + 4 * scol]) = stage[i];
+    for (int i = 0; i < 8; ++i)
+      *(f32x4*)(&tile[buf][(srow + 8 * i) * CL_STRIDE + 4 * scol]) = (live >> i) & 1 ? stage[i] : f32x4{0.f, 0.f, 0.f, 0.f};
   };
   fetch(0);
   park(0);
   __syncthreads();
-  for (int t = 0; t < taps; ++t) {
+  // One tap: the first four weight fragments are requested BEFORE the next tap's rows — loads return in order, so a
+  // fragment requested behind the rows would make the tap's first MFMA wait out their round trip.
+  auto one_tap = [&](const int t, auto more_c) {
+    constexpr bool more = decltype(more_c)::value;
     const int buf = t & 1;
-    if (t + 1 < taps) fetch(t + 1);               // in flight under this tap's MFMAs
     const float* wsrc = w_pk + (((long)t * 32 + half) * DRK_C + co) * 4;
+    f32x4 bq[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bq[g] = *(const f32x4*)(wsrc + (long)g * (2 * DRK_C * 4));
+    if constexpr (more) fetch(t + 1);             // in flight under this tap's MFMAs
     const float* a0 = &tile[buf][lr * CL_STRIDE + 4 * half];
     const float* a1 = a0 + 32 * CL_STRIDE;
-#pragma unroll 4
+#pragma unroll
     for (int g = 0; g < 16; ++g) {
-      const f32x4 b = *(const f32x4*)(wsrc + (long)g * (2 * DRK_C * 4));
+      const f32x4 b = g < 4 ? bq[g] : *(const f32x4*)(wsrc + (long)g * (2 * DRK_C * 4));
       const f32x4 x0 = *(const f32x4*)(a0 + 8 * g);
       const f32x4 x1 = *(const f32x4*)(a1 + 8 * g);
 #pragma unroll
@@ -345,11 +359,13 @@ __global__ void __launch_bounds__(256) k_conv_f32_lds(const float* __restrict__ 
         acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[j], b[j], acc[1], 0, 0, 0);
       }
     }
-    if (t + 1 < taps) {
+    if constexpr (more) {
       park(buf ^ 1);                              // the other buffer: its last readers finished before the previous barrier
       __syncthreads();
     }
-  }
+  };
+  for (int t = 0; t + 1 < taps; ++t) one_tap(t, std::true_type{});
+  one_tap(taps - 1, std::false_type{});
   const float bco = bias ? bias[co] : 0.0f;
   float rv[2][16];          // the residual, requested before the first store (see k_conv_f32)
 #pragma unroll
