@@ -178,6 +178,9 @@ __global__ void __launch_bounds__(512) k_ln_bwd(const float* __restrict__ dh, co
 // (plain 128-byte row segments), and k_wgrad_reduce adds the slabs in chunk order: the same bits on every run, and
 // plain stores move at 4-5x the rate of float atomics (MI355X_MICROARCH.md, Global float atomics).
 #define WG_SLAB (DRK_C * DRK_C)   // floats per (chunk, tap) slab
+#ifndef WG_DEPTH
+#define WG_DEPTH 4                // steps of operands in flight + 1 (the loop is unrolled by it)
+#endif
 __global__ void __launch_bounds__(256) k_conv_wgrad(const float* __restrict__ h, const float* __restrict__ dc,
                                                     float* __restrict__ slabs, float* __restrict__ bslabs, long M, int L, int taps, int dil,
                                                     int wg_rows) {
@@ -196,45 +199,45 @@ __global__ void __launch_bounds__(256) k_conv_wgrad(const float* __restrict__ h,
   const float* hp = h + (r0 + half + off) * DRK_C + 32 * w + lr;
   const float* dp = dc + (r0 + half) * DRK_C + lr;
   const int nsteps = (int)((rend - r0 + 1) >> 1);     // both half-waves run the same trip count
-  // operands of step s+1 are loaded before the MFMAs of step s (the loop is load-latency-bound otherwise)
-  auto fetch = [&](int s, float& a, f32x4& bq) {
-    a = 0.f;
-    bq = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (s < nsteps && r0 + half + 2 * s < rend) {
-      const int q = p + off;
-      if (q >= 0 && q < L) a = *hp;
-      bq = f32x4{dp[0], dp[32], dp[64], dp[96]};
-    }
+  // Operands of the next WG_DEPTH - 1 steps are in flight under the MFMAs of a step.  The loads are UNCONDITIONAL (a step
+  // past the end, or a shifted row outside its sequence, re-reads the chunk's first row) and blanked at their use: behind
+  // a branch the compiler cannot count them and waited for every load in flight at each group's first MFMA — one whole
+  // round trip per four steps.
+  const float* const hsafe = h + r0 * DRK_C + 32 * w + lr;
+  const float* const dsafe = dc + r0 * DRK_C + lr;
+  auto fetch = [&](int s, float& a, f32x4& bq, int& fl) {
+    const bool vb = s < nsteps && r0 + half + 2 * s < rend;
+    const int q = p + off;
+    const bool va = vb && q >= 0 && q < L;
+    fl = (va ? 1 : 0) | (vb ? 2 : 0);
+    const float* hq = va ? hp : hsafe;
+    const float* dq = vb ? dp : dsafe;
+    a = *hq;
+    bq = f32x4{dq[0], dq[32], dq[64], dq[96]};
     hp += 2 * DRK_C;
     dp += 2 * DRK_C;
     p += 2;
     if (p >= L) p -= L;
     if (p >= L) p -= L;
   };
-  float a0, a1, a2, a3;
-  f32x4 b0, b1, b2, b3;
+  float av[WG_DEPTH];
+  f32x4 bv[WG_DEPTH];
+  int fv[WG_DEPTH];
   f32x4 bsum = {0.f, 0.f, 0.f, 0.f};   // column sums of dc = the conv bias gradient (one wave of the centre-tap workgroup)
   const bool do_bias = bslabs && off == 0 && t == taps / 2 && w == 0;
-  fetch(0, a0, b0);
-  fetch(1, a1, b1);
-  fetch(2, a2, b2);
-  for (int s = 0; s < nsteps; s += 4) {   // 3 steps of loads in flight
-    fetch(s + 3, a3, b3);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0[j], acc[j], 0, 0, 0);
-    if (do_bias) bsum += b0;
-    fetch(s + 4, a0, b0);
+  for (int k = 0; k < WG_DEPTH - 1; ++k) fetch(k, av[k], bv[k], fv[k]);
+  for (int s = 0; s < nsteps; s += WG_DEPTH) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1[j], acc[j], 0, 0, 0);
-    if (do_bias) bsum += b1;
-    fetch(s + 5, a1, b1);
+    for (int k = 0; k < WG_DEPTH; ++k) {
+      constexpr int dummy = 0; (void)dummy;
+      fetch(s + k + WG_DEPTH - 1, av[(k + WG_DEPTH - 1) % WG_DEPTH], bv[(k + WG_DEPTH - 1) % WG_DEPTH], fv[(k + WG_DEPTH - 1) % WG_DEPTH]);
+      const float au = (fv[k] & 1) ? av[k] : 0.f;
+      const f32x4 bu = (fv[k] & 2) ? bv[k] : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2[j], acc[j], 0, 0, 0);
-    if (do_bias) bsum += b2;
-    fetch(s + 6, a2, b2);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, b3[j], acc[j], 0, 0, 0);
-    if (do_bias) bsum += b3;
+      for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(au, bu[j], acc[j], 0, 0, 0);
+      if (do_bias) bsum += bu;
+    }
   }
   if (do_bias) {
 #pragma unroll
