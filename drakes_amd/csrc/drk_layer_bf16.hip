@@ -148,15 +148,25 @@ __global__ void __launch_bounds__(256, WGS) k_layer_bf16(const LayerArgs a) {
 #pragma unroll
     for (int t = 0; t < LT_NT; ++t) pos[t] = (int)((p0 + 16 * t + pn) % (unsigned)L);
     const int own = (halo + pn) * LT_ROWB + goff;         // this lane's row of tile 0, unshifted
+    // (branch-free on purpose: as a ?: the compiler built eight exec-masked blocks per tap, and the LDS reads in flight
+    // across them were all waited for — lgkmcnt(0) — at every tap's first MFMA)
     auto addr_of = [&](int t, int s) {
-      return (unsigned)(pos[t] + s) < (unsigned)L ? own + (16 * t + s) * LT_ROWB : LT_ZERO_OFF + goff;
+      const int in = -(int)((unsigned)(pos[t] + s) < (unsigned)L);          // all ones inside [0, L)
+      const int za = LT_ZERO_OFF + goff;
+      return za + (in & (own + (16 * t + s) * LT_ROWB - za));
     };
     int cura[LT_NT];
     bf16v8 cur[LT_NT];
 #pragma unroll
+    for (int t = 0; t < LT_NT; ++t) cura[t] = addr_of(t, (a.first_tap - center) * a.dil);
+    // the first tap's fragments, pinned in tile order (as the reads inside the loop are): the wait at the loop header covers
+    // both ways into it, and with tile 0's read issued last here it became lgkmcnt(0) at EVERY tap's first MFMA
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): no scalar load (they return out of order) is pending at the loop header
+#pragma unroll
     for (int t = 0; t < LT_NT; ++t) {
-      cura[t] = addr_of(t, (a.first_tap - center) * a.dil);
       cur[t] = *(const bf16v8*)(smem + cura[t]);
+      __builtin_amdgcn_sched_barrier(0);
     }
     for (int tap = a.first_tap; tap <= last_tap; ++tap) {
       const int ntap = tap < last_tap ? tap + 1 : tap;    // (after the last tap the refills are unused)
