@@ -58,6 +58,10 @@ SIGNATURES = {
     'drk_stem_ln_bf16': [_P, _P, _P, _P, c_long, _P, _P, _P, _P, _P, _P, c_int, c_int, _P],
     'drk_gate_bf16': [_P, _P, _P, _P, _P, c_int, c_int, _P, c_long, _P],
     'drk_conv_wgrad_bf16': [_P, _P, _P, c_int, c_int, c_int, c_int, _P, c_long, _P],
+    'drk_layer_bwd_bf16': [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_long, c_int, c_int, c_int, c_int, c_int, _P],
+    'drk_head_bwd_bf16': [_P, _P, _P, _P, _P, c_long, c_int, c_int, _P],
+    'drk_conv_wgrad_bf16_multi': [_P, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, c_long, _P],
+    'drk_slab_reduce': [_P, c_int, c_long, _P, c_long, _P],
     'drk_sample_bf16': [_P, _P, _P, _P, _P, c_long, _P, _P, _P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, c_int,
                         c_uint64, c_uint64, c_int, _P],
 }
@@ -66,6 +70,8 @@ HOST_QUERIES = {
     'drk_conv_wgrad_workspace_bytes': [c_int, c_int, c_int],
     'drk_conv_wgrad_bf16_workspace_bytes': [c_int, c_int, c_int],
     'drk_gate_bf16_workspace_bytes': [],
+    'drk_conv_wgrad_bf16_multi_workspace_bytes': [c_int, c_int, c_int, c_int],
+    'drk_head_bwd_bf16_slab_floats': [],
 }
 
 _lib = None

@@ -208,16 +208,144 @@ class _BackboneFn(torch.autograd.Function):
         return (None, dseq if ctx.needs_input_grad[1] else None, None, None, *grads)
 
 
+class GradSink:
+    """Where the bf16 backward leaves everything the PARAMETER gradients need, so that they are formed once per chain of
+    forwards instead of once per forward (the optimizer reads them only after the whole backward pass,
+    finetune_reward_bp.py:88-93):
+      * per recorded forward, the bf16 operand pairs of every convolution's weight gradient — hs[i] (the LayerNorm
+        outputs the forward saved) and dcs[i] (the gated output gradients the backward produced) — by reference;
+      * per distinct sigma, one fp32 accumulator row [W] for the column-sum quantities (LayerNorm affine, conv biases, time
+        biases, the 128 -> 5 head), filled by ONE ordered slab reduction per backward call;
+      * stem weight / bias gradients, accumulated by the stem kernels' atomics.
+    flush() then runs ONE drk_conv_wgrad_bf16_multi per layer over all recorded forwards (K x B x L rows), one
+    drk_time_bwd per distinct sigma, and returns {parameter name: gradient}.  Deterministic for the conv weights (99 % of
+    the parameters)."""
+
+    def __init__(self, bb):
+        self.bb = bb
+        n = bb.num_layers
+        self.n = n
+        self.head_off = (n + 1) * 4 * C                  # layer slots 0..n-1, slot n = the head's input gradient launch
+        self.W = self.head_off + int(_lib_slab())        # + drk_head_bwd_bf16's slab
+        self.records = []                                # (B, L, hs, dcs)
+        self.groups = {}                                 # sigma key -> (sigma, temb, acc [W])
+        self.stem_dw = None
+        self.stem_db = None
+
+    def group(self, key, sigma, temb):
+        """The accumulator row of the forwards that ran at this sigma (key: its value as a Python number, known to the
+        caller without a device read; None: this forward's own row)."""
+        key = id(sigma) if key is None else key
+        g = self.groups.get(key)
+        if g is None:
+            g = (sigma, temb, torch.zeros(self.W, dtype=torch.float32, device=temb.device))
+            self.groups[key] = g
+        return g[2]
+
+    def stem(self, dev):
+        if self.stem_dw is None:
+            self.stem_dw = torch.zeros(9, V, C, dtype=torch.float32, device=dev)
+            self.stem_db = torch.zeros(1, C, dtype=torch.float32, device=dev)
+        return self.stem_dw, self.stem_db
+
+    def flush(self):
+        """-> {name: gradient} for every trainable parameter the recorded backward calls reached; clears the records."""
+        bb, n = self.bb, self.n
+        g = {}
+        if not self.groups:
+            return g
+        pk = bb.packed()
+        dev = next(iter(self.groups.values()))[2].device
+        # ---- convolution weights: one launch per layer and shape over all recorded forwards
+        dwt = torch.zeros(9 * n + 1, C, C, dtype=torch.float32, device=dev)
+        by_shape = {}
+        for B, L, hs, dcs in self.records:
+            by_shape.setdefault((B, L), []).append((hs, dcs))
+        for (B, L), recs in by_shape.items():
+            K = len(recs)
+            ptrs = torch.tensor([[[r[w][i].data_ptr() for r in recs] for i in range(n + 1)] for w in (0, 1)], dtype=torch.int64,
+                                pin_memory=True).to(dev, non_blocking=True)
+            for i in range(n):
+                ops.conv_wgrad_bf16_multi(ptrs[0, i], ptrs[1, i], K, dwt[9 * i:9 * i + 9], B, L, bb.dilation(i))
+            ops.conv_wgrad_bf16_multi(ptrs[0, n], ptrs[1, n], K, dwt[9 * n:], B, L, 0)
+        for i in range(n):
+            g[f'convs.{i}.weight'] = dwt[9 * i:9 * i + 9].permute(2, 1, 0)
+        g['final_conv.0.weight'] = dwt[9 * n:].permute(2, 1, 0)
+        # ---- column-sum quantities
+        accs = [a for _, _, a in self.groups.values()]
+        tot = accs[0] if len(accs) == 1 else torch.stack(accs).sum(0)
+        lay = tot[:self.head_off].view(n + 1, 4, C)
+        for i in range(n):
+            g[f'norms.{i}.weight'], g[f'norms.{i}.bias'] = lay[i, 0], lay[i, 1]
+            g[f'convs.{i}.bias'] = lay[i + 1, 3]            # the gate sums of the launch ABOVE layer i
+        hd = tot[self.head_off:]
+        g['final_conv.2.weight'] = hd[:V * C].view(V, C).unsqueeze(-1)
+        g['final_conv.0.bias'] = hd[V * C:(V + 1) * C]
+        g['final_conv.2.bias'] = hd[(V + 1) * C:(V + 1) * C + V]
+        # ---- stem
+        if self.stem_dw is not None:
+            g['linear.weight'] = self.stem_dw.permute(2, 1, 0)
+            g['linear.bias'] = self.stem_db[0]
+        # ---- time path: one backward per distinct sigma (the time-bias gradients of its forwards, summed)
+        d_dense_w = torch.zeros(n, C, C, dtype=torch.float32, device=dev)
+        d_dense_b = torch.zeros(n, C, dtype=torch.float32, device=dev)
+        d_lin_w = torch.zeros(C, C, dtype=torch.float32, device=dev)
+        d_lin_b = torch.zeros(C, dtype=torch.float32, device=dev)
+        for sigma, temb, acc in self.groups.values():
+            dtb = acc[:n * 4 * C].view(n, 4, C)[:, 2].contiguous().view(1, n, C)
+            ops.time_bwd(dtb, sigma, pk['four_W'], temb, pk['dense_w'], d_dense_w, d_dense_b, d_lin_w, d_lin_b,
+                         torch.zeros(1, C, dtype=torch.float32, device=dev))
+        g['time_embedder.1.weight'], g['time_embedder.1.bias'] = d_lin_w, d_lin_b
+        for i in range(n):
+            g[f'time_layers.{i}.dense.weight'], g[f'time_layers.{i}.dense.bias'] = d_dense_w[i], d_dense_b[i]
+        self.records, self.groups, self.stem_dw, self.stem_db = [], {}, None, None
+        return g
+
+
+def _lib_slab():
+    from . import _lib
+    return _lib.load().drk_head_bwd_bf16_slab_floats()
+
+
+class _ChainFn(torch.autograd.Function):
+    """The graph node through which a GradSink's gradients reach the parameters: its output (one element, never read)
+    is handed to every forward of the chain in place of the parameters, so autograd runs this backward once, after the
+    last of them."""
+
+    @staticmethod
+    def forward(ctx, sink, *params):
+        ctx.sink = sink
+        ctx.names = [k for k, _ in sink.bb.named_parameters()]
+        return params[0].new_zeros(1)
+
+    @staticmethod
+    def backward(ctx, _g):
+        g = ctx.sink.flush()
+        return (None, *[g.get(k) if ctx.needs_input_grad[1 + j] else None for j, k in enumerate(ctx.names)])
+
+
+def grad_chain(bb):
+    """(sink, anchor) for a chain of differentiable bf16 forwards between two optimizer steps (the K Gumbel-softmax steps
+    of _sample_finetune_gradient): pass both to backbone_with_grad(..., dtype='bf16', flat=anchor, sink=sink)."""
+    sink = GradSink(bb)
+    return sink, _ChainFn.apply(sink, *bb.parameters())
+
+
 class _BackboneBf16Fn(torch.autograd.Function):
     """logits = CNNModel(seq, sigma) on the bf16-MFMA layer kernels, differentiable: bf16 LayerNorm outputs and conv
     operands (forward, input gradient, weight gradient), fp32 accumulation, fp32 residual stream and residual-gradient
     stream, fp32 LayerNorm statistics and backward, fp32 stem / 128->5 head / time path.  Saved per forward: the 21
     residual snapshots (fp32), the 21 LayerNorm outputs (bf16: the weight gradient's operand), LayerNorm statistics and
-    uint8 ReLU masks."""
+    uint8 ReLU masks.
+    Backward (round 3): ONE launch per layer — drk_layer_bwd_bf16 = input gradient + LayerNorm backward + residual add +
+    the gate of the layer below — and the parameter gradients deferred to a GradSink (one weight-gradient launch per
+    layer over the whole chain).  A per-row time bias (per-row sigma) takes the round-2 launch sequence."""
 
     @staticmethod
-    def forward(ctx, bb, seq, sigma, flat_mode, *params):
-        ctx.flat_mode = bool(flat_mode)
+    def forward(ctx, bb, seq, sigma, sink, *params):
+        ctx.sink, ctx.sigma_key = (sink if isinstance(sink, GradSink) else sink[0], None if isinstance(sink, GradSink) else sink[1]) \
+            if sink is not None else (None, None)
+        sink = ctx.sink
         from . import fastpath
         pk, st = bb.packed(), fastpath._packed(bb)
         vec, wstream = st['vecs'], st['wstream']
@@ -231,6 +359,7 @@ class _BackboneBf16Fn(torch.autograd.Function):
         temb = ops.time_embed_fwd(sigma, pk['four_W'], pk['temb_w'], pk['temb_b'])
         tbias = ops.time_bias_fwd(temb, pk['dense_w'], pk['dense_b'])
         tb_stride = tbias.stride(0) if nb == B and B > 1 else 0
+        assert sink is None or not tb_stride, 'a gradient chain shares one sigma per forward'
         f32 = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
         b16 = lambda: torch.empty(B, L, C, dtype=torch.bfloat16, device=dev)
         feats = [ops.stem_fwd(seq, pk['stem_w'], pk['stem_b'])]
@@ -262,6 +391,60 @@ class _BackboneBf16Fn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dlogits):
+        if ctx.tb_stride:
+            return _BackboneBf16Fn._backward_unfused(ctx, dlogits)
+        from . import fastpath
+        bb, pk, seq = ctx.bb, ctx.pk, ctx.seq
+        feats, hs, means, rstds, masks, y = ctx.feats, ctx.hs, ctx.means, ctx.rstds, ctx.masks, ctx.y
+        B, L = seq.shape[0], seq.shape[1]
+        M, n = B * L, bb.num_layers
+        dev = dlogits.device
+        dlogits = dlogits.contiguous()
+        want_w = any(ctx.needs_input_grad[4:])     # a frozen model (the KL reference model) only passes the input gradient on
+        wT = fastpath._packed_T(bb)
+        sink = ctx.sink if ctx.sink is not None else (GradSink(bb) if want_w else None)
+        b16 = lambda: torch.empty(B, L, C, dtype=torch.bfloat16, device=dev)
+        P, W = None, 0
+        if want_w:
+            W, nwg = sink.W, (M + 127) // 128
+            P = ops.workspace(nwg * W * 4, dev)      # [workgroup][W]: every slot is written by exactly one launch below
+        slot = lambda i: P[4 * C * i:] if want_w else None
+        # head: 128 -> 5 conv and final_conv.0's ReLU in one pass, then final_conv.0's input gradient with the gate of the
+        # last residual layer in its epilogue
+        dcs = [None] * (n + 1)
+        dcs[n] = ops.head_bwd_bf16(dlogits, y, pk['head2_w'], b16(), P[sink.head_off:] if want_w else None, W)
+        gr = torch.empty_like(y)                      # the residual-gradient stream, updated in place layer by layer
+        pong = [b16(), b16()] if not want_w else None
+        nxt = lambda i: b16() if want_w else pong[i & 1]
+        dcs[n - 1] = nxt(n - 1)
+        ops.layer_bwd_bf16(dcs[n], wT[9 * n:], gr, next_mask=masks[n - 1], dc_next=dcs[n - 1], partials=slot(n), part_stride=W,
+                           taps=1, dilation=0)
+        for i in reversed(range(n)):
+            if i:
+                dcs[i - 1] = nxt(i - 1)
+            ops.layer_bwd_bf16(dcs[i], wT[9 * i:], gr, feat=feats[i], tbias=ctx.tbias[0, i], gamma=pk['ln_g'][i], mean=means[i],
+                               rstd=rstds[i], gr=gr, next_mask=masks[i - 1] if i else None, dc_next=dcs[i - 1] if i else None,
+                               partials=slot(i), part_stride=W, taps=9, dilation=bb.dilation(i))
+        # stem: the fp32 kernels
+        dpre = ops.relu_bwd(gr, feats[0], out=gr)
+        dseq = torch.empty_like(seq) if seq.dtype != torch.int64 else None
+        if want_w:
+            ops.slab_reduce(P, nwg, W, sink.group(ctx.sigma_key, ctx.sigma, ctx.temb), W)
+            dw_t, db = sink.stem(dev)
+            ops.colsum128(dpre, 1, M, db)
+            ops.stem_bwd(dpre, seq, pk['stem_w'], dw_t, dseq)
+            sink.records.append((B, L, hs, dcs))
+        elif dseq is not None:
+            ops.stem_bwd(dpre, seq, pk['stem_w'], torch.zeros(9, V, C, dtype=torch.float32, device=dev), dseq)
+        ctx.feats = ctx.hs = ctx.masks = ctx.means = ctx.rstds = ctx.y = None
+        dseq = dseq if ctx.needs_input_grad[1] else None
+        if ctx.sink is not None or not want_w:        # the chain's _ChainFn hands the parameters their gradients
+            return (None, dseq, None, None) + (None,) * len(ctx.needs_input_grad[4:])
+        g = sink.flush()
+        return (None, dseq, None, None, *[g.get(k) if ctx.needs_input_grad[4 + j] else None for j, k in enumerate(ctx.names)])
+
+    @staticmethod
+    def _backward_unfused(ctx, dlogits):
         from . import fastpath
         bb, pk, seq = ctx.bb, ctx.pk, ctx.seq
         feats, hs, means, rstds, masks, y = ctx.feats, ctx.hs, ctx.means, ctx.rstds, ctx.masks, ctx.y
@@ -329,23 +512,24 @@ class _BackboneBf16Fn(torch.autograd.Function):
         for i in range(n):
             g[f'time_layers.{i}.dense.weight'], g[f'time_layers.{i}.dense.bias'] = d_dense_w[i], d_dense_b[i]
         ctx.feats = ctx.hs = ctx.masks = ctx.means = ctx.rstds = ctx.y = None
-        if ctx.flat_mode:
-            return (None, dseq if ctx.needs_input_grad[1] else None, None, None,
-                    _flat_grad(ctx, 'bf16', g, zeros, want_w, nb) if want_w else None)
         grads = [g.get(k) if ctx.needs_input_grad[4 + j] else None for j, k in enumerate(ctx.names)]
         return (None, dseq if ctx.needs_input_grad[1] else None, None, None, *grads)
 
 
-def backbone_with_grad(bb, seq, sigma, dtype='fp32', flat=None):
+def backbone_with_grad(bb, seq, sigma, dtype='fp32', flat=None, sink=None, sigma_key=None):
     """dtype 'bf16': the bf16-MFMA layer kernels (gradients within the bf16 bar); 'fp32': the exact-fp32 kernels;
     'bf16x3': those with the convolutions at fp32 grade on the bf16 matrix cores (read from bb.train_dtype).
-    flat: flat_params(bb), built once by a caller that runs many forwards per backward pass (see there)."""
+    flat: flat_params(bb), built once by a caller that runs many forwards per backward pass (see there); on the bf16 path
+    (sink, flat) = grad_chain(bb) instead, and sigma_key = sigma's value as a Python number when the caller knows it."""
     if dtype is True:
         dtype = 'bf16'
-    fn = _BackboneBf16Fn if dtype == 'bf16' else _BackboneFn
+    if dtype == 'bf16':      # sink, flat = grad_chain(bb): parameter gradients deferred to the end of the chain
+        if sink is not None:
+            return _BackboneBf16Fn.apply(bb, seq, sigma, (sink, sigma_key), flat)
+        return _BackboneBf16Fn.apply(bb, seq, sigma, None, *bb.parameters())
     if flat is not None:
-        return fn.apply(bb, seq, sigma, True, flat)
-    return fn.apply(bb, seq, sigma, False, *bb.parameters())
+        return _BackboneFn.apply(bb, seq, sigma, True, flat)
+    return _BackboneFn.apply(bb, seq, sigma, False, *bb.parameters())
 
 
 class _SubsFn(torch.autograd.Function):

@@ -61,6 +61,14 @@ struct LayerArgs {
   const float* head_w;      // drk_head_bf16 only: final_conv.2 [5][128] / [5]; the 128 -> 5 projection of the ReLU output
   const float* head_b;      //   is taken from the tile while it is on the chip, feat_out is not written
   float* logits;            //   float32 [M][5]
+  // MODE 1 (drk_layer_bwd_bf16): h = dc of this layer, wfrag = its transposed stream, feat = the LayerNorm's INPUT, tbias /
+  // gamma = that LayerNorm's (shared time bias only), mean_out / rstd_out are READ (the forward's statistics)
+  const float* gr;          // dL/dfeat arriving through the residual branch, fp32 [M][128] (NULL: none)
+  float* gout;              // dL/d(LayerNorm input) + gr, fp32 [M][128] (may be gr)
+  const unsigned char* next_mask;   // ReLU gate of the layer below, uint8 [M][128] (NULL: no dc_next)
+  char* dc_next;            // bf16 [M][128] = bf16(gout * next_mask)
+  float* partials;          // [gridDim.x] slabs of part_stride floats; this launch fills [4][128] of its workgroup's slab:
+  long part_stride;         //   column sums over its rows of dh * xhat, dh, dx, gated gout (NULL: not wanted)
 };
 
 // LDS: TROWS rows of 272 B (two 128-row tap buffers, or one halo tile), then the LayerNorm partials, whose first 272
@@ -70,7 +78,7 @@ struct LayerArgs {
 // fetched ONCE; a tap is a row offset, and a lane whose shifted position leaves [0, L) reads the all-zero row instead
 // (sequence boundaries fall anywhere inside a tile).  No barrier inside the tap loop.
 // !HALO (dilation 64): each tap's 128 shifted rows are fetched separately, double-buffered.
-template <bool HALO, int TROWS, int WGS, bool PRE>
+template <bool HALO, int TROWS, int WGS, bool PRE, int MODE = 0>
 __global__ void __launch_bounds__(256, WGS) k_layer_bf16(const LayerArgs a) {
   constexpr int LT_TILE_BYTES = TROWS * LT_ROWB, LT_ZERO_OFF = LT_TILE_BYTES;
   __shared__ __attribute__((aligned(16))) char smem[LT_TILE_BYTES + LT_ROWS * LT_PART_STRIDE * 4];
@@ -255,6 +263,160 @@ __global__ void __launch_bounds__(256, WGS) k_layer_bf16(const LayerArgs a) {
   {
 #pragma clang fp contract(fast)
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (MODE == 1) {
+    // ---- LayerNorm backward + residual add + hand-over to the layer below (drk_train_f32.hip::k_ln_bwd's arithmetic on
+    // the tile while it is on the chip).  acc = dh = dL/dh of this layer's LayerNorm output;  xhat = (feat + tbias - mean)
+    // * rstd;  dyg = dh * gamma;  dx = rstd * (dyg - mean_c(dyg) - xhat * mean_c(dyg * xhat));  gout = dx + gr;
+    // dc_next = bf16(gout * next_mask).  Column sums of dh * xhat (dgamma), dh (dbeta), dx (time bias), gated gout (the
+    // lower layer's conv bias) leave as one [4][128] partial per workgroup, summed in order by the caller.
+    const bool ln = a.ln;
+    const f32x4 tb0 = ln ? *(const f32x4*)(a.tbias + ch0) : zero4, tb1 = ln ? *(const f32x4*)(a.tbias + ch0 + 16) : zero4;
+    const f32x4 gm0 = ln ? *(const f32x4*)(a.gamma + ch0) : zero4, gm1 = ln ? *(const f32x4*)(a.gamma + ch0 + 16) : zero4;
+    float mu[LT_NT], rs[LT_NT];
+#pragma unroll
+    for (int t = 0; t < LT_NT; ++t) {
+      long row = r0 + 16 * t + pn;
+      row = row < a.M ? row : a.M - 1;
+      mu[t] = ln ? a.mean_out[row] : 0.f;
+      rs[t] = ln ? a.rstd_out[row] : 0.f;
+    }
+    f32x4 xh[LT_NT][2];
+    if constexpr (!PRE) {
+#pragma unroll
+      for (int t = 0; t < LT_NT; ++t) {
+        long row = r0 + 16 * t + pn;
+        row = row < a.M ? row : a.M - 1;
+        xh[t][0] = ln ? *(const f32x4*)(a.feat + row * DRK_C + ch0) : zero4;
+        xh[t][1] = ln ? *(const f32x4*)(a.feat + row * DRK_C + ch0 + 16) : zero4;
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < LT_NT; ++t) {
+        xh[t][0] = res[t][0];
+        xh[t][1] = res[t][1];
+      }
+    }
+    f32x4 sg0 = zero4, sg1 = zero4, sb0 = zero4, sb1 = zero4;
+    __syncthreads();   // every wave is past its reads of the activation tiles (and of the all-zero row)
+    if (ln) {
+      float y[LT_NT];
+#pragma unroll
+      for (int t = 0; t < LT_NT; ++t) {
+        const bool ok = r0 + 16 * t + pn < a.M;
+        const f32x4 d0 = ok ? acc[t][0] : zero4, d1 = ok ? acc[t][1] : zero4;
+        const f32x4 h0 = (xh[t][0] + tb0 - mu[t]) * rs[t], h1 = (xh[t][1] + tb1 - mu[t]) * rs[t];
+        sg0 += d0 * h0;
+        sg1 += d1 * h1;
+        sb0 += d0;
+        sb1 += d1;
+        const f32x4 y0 = d0 * gm0, y1 = d1 * gm1;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          s1 += y0[i] + y1[i];
+          s2 += y0[i] * h0[i] + y1[i] * h1[i];
+        }
+        acc[t][0] = y0;
+        acc[t][1] = y1;
+        xh[t][0] = h0;
+        xh[t][1] = h1;
+        const u32x2 sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(s1), __float_as_uint(s2), false, false);
+        y[t] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+      }
+      const int slot = (g >> 1) * 4 + ct;
+#pragma unroll
+      for (int t = 0; t < LT_NT; t += 2) {
+        const u32x2 sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(y[t]), __float_as_uint(y[t + 1]), false, false);
+        const int tile_i = (g & 1) ? t + 1 : t;
+        part[(16 * tile_i + pn) * LT_PART_STRIDE + slot] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < LT_NT; ++t) {
+        const bool ok = r0 + 16 * t + pn < a.M;
+        acc[t][0] = ok ? acc[t][0] : zero4;
+        acc[t][1] = ok ? acc[t][1] : zero4;
+      }
+    }
+    // the residual-branch gradient and the lower layer's gate: requested ahead of the barrier
+    f32x4 gv[LT_NT][2];
+    unsigned mk[LT_NT][2];
+#pragma unroll
+    for (int t = 0; t < LT_NT; ++t) {
+      const long row = r0 + 16 * t + pn;
+      const bool ok = row < a.M;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        gv[t][s] = (a.gr && ok) ? *(const f32x4*)(a.gr + row * DRK_C + ch0 + 16 * s) : zero4;
+        mk[t][s] = (a.next_mask && ok) ? *(const unsigned*)(a.next_mask + row * DRK_C + ch0 + 16 * s) : 0u;
+      }
+    }
+    __syncthreads();
+    f32x4 sx0 = zero4, sx1 = zero4, sc0 = zero4, sc1 = zero4;
+#pragma unroll
+    for (int t = 0; t < LT_NT; ++t) {
+      const long row = r0 + 16 * t + pn;
+      const bool ok = row < a.M;
+      f32x4 dx0 = acc[t][0], dx1 = acc[t][1];
+      if (ln) {
+        const float* pp = part + (16 * t + pn) * LT_PART_STRIDE;
+        const f32x4 q1 = *(const f32x4*)(pp), q2 = *(const f32x4*)(pp + 4);
+        const float m1 = ((q1[0] + q1[1]) + (q1[2] + q1[3])) * (1.0f / 128.0f);
+        const float m2 = ((q2[0] + q2[1]) + (q2[2] + q2[3])) * (1.0f / 128.0f);
+        dx0 = (dx0 - m1 - xh[t][0] * m2) * rs[t];
+        dx1 = (dx1 - m1 - xh[t][1] * m2) * rs[t];
+      }
+      sx0 += dx0;
+      sx1 += dx1;
+      const f32x4 o0 = dx0 + gv[t][0], o1 = dx1 + gv[t][1];
+      if (ok && a.gout) {
+        *(f32x4*)(a.gout + row * DRK_C + ch0) = o0;
+        *(f32x4*)(a.gout + row * DRK_C + ch0 + 16) = o1;
+      }
+      if (a.dc_next) {
+        const unsigned m0 = mk[t][0], m1b = mk[t][1];
+        const f32x4 v0 = {(m0 & 0xffu) ? o0[0] : 0.f, (m0 & 0xff00u) ? o0[1] : 0.f, (m0 & 0xff0000u) ? o0[2] : 0.f, (m0 & 0xff000000u) ? o0[3] : 0.f};
+        const f32x4 v1 = {(m1b & 0xffu) ? o1[0] : 0.f, (m1b & 0xff00u) ? o1[1] : 0.f, (m1b & 0xff0000u) ? o1[2] : 0.f, (m1b & 0xff000000u) ? o1[3] : 0.f};
+        sc0 += v0;
+        sc1 += v1;
+        char* rowp = tile0 + (16 * t + pn) * LT_ROWB + 2 * ch0;
+        bf16v4 pk;
+        pk[0] = (__bf16)v0[0]; pk[1] = (__bf16)v0[1]; pk[2] = (__bf16)v0[2]; pk[3] = (__bf16)v0[3];
+        *(bf16v4*)(rowp) = pk;
+        pk[0] = (__bf16)v1[0]; pk[1] = (__bf16)v1[1]; pk[2] = (__bf16)v1[2]; pk[3] = (__bf16)v1[3];
+        *(bf16v4*)(rowp + 32) = pk;
+      }
+    }
+    if (a.dc_next) {
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const long row = r0 + srow + 16 * i;
+        if (row < a.M) *(f32x4*)(a.dc_next + row * 256 + 16 * scol) = *(const f32x4*)(tile0 + (srow + 16 * i) * LT_ROWB + 16 * scol);
+      }
+    }
+    if (a.partials) {
+      // sum over the 16 rows a lane group holds (lanes 16 g + n, n = 0..15: one DPP row), in a fixed order
+      f32x4 q[8] = {sg0, sg1, sb0, sb1, sx0, sx1, sc0, sc1};
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float v = q[k][i];
+          v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0xB1, 0xF, 0xF, false));    // quad_perm [1,0,3,2]
+          v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x4E, 0xF, 0xF, false));    // quad_perm [2,3,0,1]
+          v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x141, 0xF, 0xF, false));   // row_half_mirror
+          v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x140, 0xF, 0xF, false));   // row_mirror
+          q[k][i] = v;
+        }
+      if (n == 0) {
+        float* dst = a.partials + (long)blockIdx.x * a.part_stride + ch0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) *(f32x4*)(dst + (k >> 1) * DRK_C + 16 * (k & 1)) = q[k];
+      }
+    }
+    return;
+  }
   // a time bias shared by the batch (the sampler's case) is requested here, two barriers before its use
   const bool tb_shared = a.ln && a.h_out && a.tb_stride == 0;
   const f32x4 tbs0 = tb_shared ? *(const f32x4*)(a.tbias + ch0) : zero4, tbs1 = tb_shared ? *(const f32x4*)(a.tbias + ch0 + 16) : zero4;
@@ -540,6 +702,7 @@ extern "C" int drk_layer_bf16(const void* h, const float* feat, float* feat_out,
   LayerArgs a;
   a.mask_out = relu_mask; a.mean_out = mean; a.rstd_out = rstd; a.relu = relu ? 1 : 0;
   a.head_w = nullptr; a.head_b = nullptr; a.logits = nullptr;
+  a.gr = nullptr; a.gout = nullptr; a.next_mask = nullptr; a.dc_next = nullptr; a.partials = nullptr; a.part_stride = 0;
   a.h = (const char*)h; a.feat = feat; a.feat_out = feat_out; a.h_out = (char*)h_out; a.wfrag = (const char*)wfrag;
   a.bias = bias; a.tbias = tbias; a.tb_stride = tb_stride; a.gamma = gamma; a.beta = beta;
   a.M = (long)B * L; a.L = L; a.taps = taps; a.dil = dilation; a.ln = ln ? 1 : 0;
@@ -555,6 +718,37 @@ extern "C" int drk_layer_bf16(const void* h, const float* feat, float* feat_out,
     hipLaunchKernelGGL((k_layer_bf16<true, 256, 2, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
   else                               // one fetch per tap
     hipLaunchKernelGGL((k_layer_bf16<false, 256, 2, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  DRK_CHECK_LAUNCH();
+  return DRK_OK;
+}
+
+extern "C" int drk_layer_bwd_bf16(const void* dc, const void* wfrag_t, const float* feat, const float* tbias, const float* gamma,
+                                  const float* mean, const float* rstd, const float* gr, float* gout,
+                                  const unsigned char* next_mask, void* dc_next, float* partials, long part_stride, int B,
+                                  int L, int taps, int dilation, int ln, void* stream) {
+  DRK_SHAPE_GUARD("drk_layer_bwd_bf16");
+  LARGCHECK(dc && wfrag_t && gout && taps >= 1 && (taps & 1) && dilation >= 0, "drk_layer_bwd_bf16");
+  LARGCHECK(!ln || (feat && tbias && gamma && mean && rstd), "drk_layer_bwd_bf16 (ln = 1 needs feat, tbias, gamma, mean, rstd)");
+  LARGCHECK(!next_mask == !dc_next, "drk_layer_bwd_bf16 (next_mask and dc_next come together)");
+  LARGCHECK((const void*)dc != (const void*)dc_next, "drk_layer_bwd_bf16 (dc and dc_next must be distinct buffers)");
+  LARGCHECK(!partials || (part_stride >= 4 * DRK_C && (part_stride & 3) == 0 && ((uintptr_t)partials & 15) == 0),
+            "drk_layer_bwd_bf16 (partials: 16-byte aligned slabs of part_stride >= 512 floats)");
+  LayerArgs a;
+  a.mask_out = nullptr; a.mean_out = const_cast<float*>(mean); a.rstd_out = const_cast<float*>(rstd); a.relu = 0;
+  a.head_w = nullptr; a.head_b = nullptr; a.logits = nullptr;
+  a.h = (const char*)dc; a.feat = ln ? feat : nullptr; a.feat_out = nullptr; a.h_out = nullptr; a.wfrag = (const char*)wfrag_t;
+  a.bias = nullptr; a.tbias = tbias; a.tb_stride = 0; a.gamma = gamma; a.beta = nullptr;
+  a.M = (long)B * L; a.L = L; a.taps = taps; a.dil = dilation; a.ln = ln ? 1 : 0;
+  a.gr = gr; a.gout = gout; a.next_mask = next_mask; a.dc_next = (char*)dc_next; a.partials = partials; a.part_stride = part_stride;
+  const int center = taps / 2;
+  int reach = center;
+  if (dilation > 0 && (L - 1) / dilation < reach) reach = (L - 1) / dilation;
+  a.first_tap = center - reach;
+  const dim3 grid((unsigned)((a.M + LT_ROWS - 1) / LT_ROWS));
+  if (LT_ROWS + 2 * center * dilation <= 256)
+    hipLaunchKernelGGL((k_layer_bf16<true, 256, 1, true, 1>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL((k_layer_bf16<false, 256, 1, false, 1>), grid, dim3(256), 0, (hipStream_t)stream, a);
   DRK_CHECK_LAUNCH();
   return DRK_OK;
 }
@@ -592,6 +786,7 @@ extern "C" int drk_head_bf16(const void* h, const void* wfrag, const float* bias
   a.bias = bias; a.tbias = nullptr; a.tb_stride = 0; a.gamma = nullptr; a.beta = nullptr;
   a.M = (long)B * L; a.L = L; a.taps = 1; a.dil = 0; a.ln = 0; a.first_tap = 0;
   a.head_w = head_w; a.head_b = head_b; a.logits = logits;
+  a.gr = nullptr; a.gout = nullptr; a.next_mask = nullptr; a.dc_next = nullptr; a.partials = nullptr; a.part_stride = 0;
   const dim3 grid((unsigned)((a.M + LT_ROWS - 1) / LT_ROWS));
   hipLaunchKernelGGL((k_layer_bf16<true, 256, 2, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
   DRK_CHECK_LAUNCH();

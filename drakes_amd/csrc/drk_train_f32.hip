@@ -860,6 +860,13 @@ int drk_slab_reduce_launch(const float* slabs, int n_slabs, long stride, float* 
   return DRK_OK;
 }
 
+extern "C" int drk_slab_reduce(const float* slabs, int n_slabs, long stride, float* out, long n, void* stream) {
+  if (n_slabs < 0 || n < 0 || (n & 3) || (n && (!slabs || !out)) || (((uintptr_t)slabs | (uintptr_t)out) & 15) || (stride & 3))
+    return drk_set_error_msg(DRK_EINVAL, "drk_slab_reduce: n % 4 == 0, stride % 4 == 0, 16-byte aligned pointers");
+  if (n == 0 || n_slabs == 0) return DRK_OK;
+  return drk_slab_reduce_launch(slabs, n_slabs, stride, out, n, (hipStream_t)stream);
+}
+
 // Row chunk of the split-K weight gradient: the smallest 64 * 2^k rows with at most WG_MAX_SLABS (chunk, tap)
 // workgroups — two co-resident workgroups per CU (the loop is load-latency-bound: a second workgroup hides it; one
 // round of 1024-row workgroups measured 27 % slower at B = 128), and a bounded workspace (one 64-KB slab each).

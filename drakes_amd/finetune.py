@@ -70,6 +70,7 @@ def sample_finetune_gradient(model, num_steps=None, eps=1e-5, eval_sp_size=None,
     model._soft_logits_cache = {}
     shared = None
     flat = None                                 # the parameters as one vector: one gradient per soft step, not 129
+    sink = None                                 # bf16 soft steps: parameter gradients deferred to the end of the chain
     n_hard = max(num_steps - trunc, 0)
     first = 0
     if model.hip_dtype == 'bf16' and n_hard > 0 and L <= 224:
@@ -105,8 +106,14 @@ def sample_finetune_gradient(model, num_steps=None, eps=1e-5, eval_sp_size=None,
                 x = F.one_hot(x, num_classes=model.vocab_size).to(torch.float32)
             sig = torch.full((1,), sigma_t if model.time_conditioning else 0.0, dtype=torch.float32, device=dev)
             if flat is None and torch.is_grad_enabled() and getattr(model, 'hip_flat_grads', True):
-                flat = autograd.flat_params(bb)
-            logits = autograd.backbone_with_grad(bb, x, sig, bb.train_dtype, flat=flat if torch.is_grad_enabled() else None)
+                if soft_bf16:
+                    sink, flat = autograd.grad_chain(bb)
+                else:
+                    flat = autograd.flat_params(bb)
+            grad_on = torch.is_grad_enabled()
+            logits = autograd.backbone_with_grad(bb, x, sig, bb.train_dtype, flat=flat if grad_on else None,
+                                                 sink=sink if grad_on else None,
+                                                 sigma_key=float(sigma_t) if model.time_conditioning else 0.0)
             last_x = x
             model._soft_logits_cache[id(x)] = (x, logits, bb._weights_key())
             x, copy_flag = autograd.soft_step_with_grad(logits, x, mc_t, mc_s, temp, copy_flag_temp, seed, i,

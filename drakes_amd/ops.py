@@ -400,6 +400,44 @@ def conv_wgrad_bf16(h, dc, dwt, dilation, ws=None):
               ws.numel() * 4, _stream())
 
 
+def layer_bwd_bf16(dc, wfrag_t, gout, *, feat=None, tbias=None, gamma=None, mean=None, rstd=None, gr=None, next_mask=None,
+                   dc_next=None, partials=None, part_stride=0, taps=9, dilation=1):
+    """One launch of drk_layer_bwd_bf16 (include/drakes_hip.h): the convolution's input gradient with the LayerNorm
+    backward (on when gamma is given), the residual add and the gate of the layer below in its epilogue.  partials: a view
+    starting at this launch's [4][128] slot of workgroup 0's slab; part_stride floats between workgroups' slabs."""
+    B, L, _ = dc.shape
+    _lib.call('drk_layer_bwd_bf16', _b16(dc, 'dc'), _b16(wfrag_t, 'wfrag_t'), _f(feat, 'feat'), _raw(tbias), _raw(gamma),
+              _f(mean, 'mean'), _f(rstd, 'rstd'), _f(gr, 'gr'), _f(gout, 'gout'), _dev_ptr(next_mask, torch.uint8, 'next_mask'),
+              _b16(dc_next, 'dc_next'), _raw(partials), part_stride, B, L, taps, dilation, 1 if gamma is not None else 0,
+              _stream())
+    return gout
+
+
+def head_bwd_bf16(dlogits, y, w, dc, partials=None, part_stride=0):
+    """dc = bf16((dlogits x final_conv.2) * (y > 0)) and the per-workgroup partial sums of final_conv.2's weight / bias and
+    final_conv.0's bias gradients (drk_head_bwd_bf16)."""
+    B, L, _ = y.shape
+    _lib.call('drk_head_bwd_bf16', _f(dlogits, 'dlogits'), _f(y, 'y'), _f(w, 'w'), _b16(dc, 'dc'), _raw(partials), part_stride,
+              B, L, _stream())
+    return dc
+
+
+def conv_wgrad_bf16_multi(h_ptrs, dc_ptrs, n_seg, dwt, B, L, dilation, ws=None):
+    """dwt [taps,128,128] += the weight gradient summed over n_seg recorded (h, dc) pairs of shape [B,L,128] bf16, in one
+    launch; h_ptrs / dc_ptrs: int64 device tensors [n_seg] of device addresses."""
+    taps = dwt.shape[0]
+    if ws is None:
+        ws = workspace(_lib.load().drk_conv_wgrad_bf16_multi_workspace_bytes(n_seg, B, L, taps), dwt.device)
+    _lib.call('drk_conv_wgrad_bf16_multi', _i(h_ptrs, 'h_ptrs'), _i(dc_ptrs, 'dc_ptrs'), n_seg, _f(dwt, 'dwt'), B, L, taps,
+              dilation, _f(ws, 'workspace'), ws.numel() * 4, _stream())
+
+
+def slab_reduce(slabs, n_slabs, stride, out, n):
+    """out[:n] += slabs[0][:n] + slabs[1][:n] + ... in order (slab s at element s * stride of `slabs`)."""
+    _lib.call('drk_slab_reduce', _raw(slabs), n_slabs, stride, _raw(out), n, _stream())
+    return out
+
+
 # ---- weight layouts the kernels read (pure index permutations) --------------------------------
 def pack_conv_weight_f32(w):
     """[co][ci][taps] -> [taps][ci/4][co][4] (drk_conv_fwd_f32's w_pk)."""

@@ -308,6 +308,43 @@ long drk_conv_wgrad_bf16_workspace_bytes(int B, int L, int taps);
 int drk_conv_wgrad_bf16(const void* h, const void* dc, float* dwt, int B, int L, int taps, int dilation, void* workspace,
                         long workspace_bytes, void* stream);
 
+/* ---- round 3: the bf16 backward as ONE launch per layer, parameter gradients deferred -------------------------------
+ * (reference: torch autograd over models/dnaconv.py:88-101 inside the K Gumbel-softmax steps of
+ * _sample_finetune_gradient, diffusion_gosai_update.py:589-630; the optimizer reads the gradients only after the whole
+ * chain's backward, finetune_reward_bp.py:88-93, so weight gradients are taken over all recorded steps at once.) */
+/* One residual layer's backward except its weight gradient: the convolution's input gradient (drk_layer_bf16 with
+ * relu = 0 on wfrag_t, the transposed tap-flipped stream) with the LayerNorm backward, the residual add and the
+ * hand-over to the layer below in its epilogue (what drk_ln_bwd does in a second launch):
+ *   dh = conv_T(dc);  xhat = (feat + tbias - mean) * rstd;  dyg = dh * gamma;
+ *   dx = rstd * (dyg - mean_c(dyg) - xhat * mean_c(dyg * xhat))          (ln = 1;  ln = 0: dx = dh)
+ *   gout = dx + gr (gr NULL: + 0; gout may be gr);  dc_next = bf16(gout * next_mask) (both NULL: none)
+ * dc, dc_next bf16 [B*L][128], distinct; feat, gr, gout float32 [B*L][128]; tbias, gamma [128] (time bias shared by
+ * the batch); mean, rstd float32 [B*L] as saved by drk_layer_bf16 / drk_ln_fwd_bf16; next_mask uint8 [B*L][128].
+ * partials (optional): workgroup w (128 rows each, ceil(B*L / 128) of them) writes [4][128] floats at
+ * partials + w * part_stride: the column sums over its rows of dh * xhat (dgamma), dh (dbeta), dx (time bias), gated
+ * gout (the lower layer's conv bias gradient); the caller adds the slabs in order (drk_slab_reduce). */
+int drk_layer_bwd_bf16(const void* dc, const void* wfrag_t, const float* feat, const float* tbias, const float* gamma,
+                       const float* mean, const float* rstd, const float* gr, float* gout,
+                       const unsigned char* next_mask, void* dc_next, float* partials, long part_stride, int B, int L,
+                       int taps, int dilation, int ln, void* stream);
+/* Backward of the 128 -> 5 output conv through final_conv.0's ReLU (models/dnaconv.py:61-63) in one pass:
+ * dc = bf16((dlogits x w) * (y > 0)), bf16 [B*L][128] (w = final_conv.2 [5][128], y = the saved ReLU output, float32);
+ * partials (optional): workgroup w (128 rows each) writes drk_head_bwd_bf16_slab_floats() = 776 floats at
+ * partials + w * part_stride: dw2 [5][128] = sum_rows dlogits[v] * y[c], db0 [128] = column sums of the fp32 gated
+ * gradient (final_conv.0's bias), db2 [5] = column sums of dlogits, 3 zeros. */
+long drk_head_bwd_bf16_slab_floats(void);
+int drk_head_bwd_bf16(const float* dlogits, const float* y, const float* w, void* dc, float* partials, long part_stride,
+                      int B, int L, void* stream);
+/* drk_conv_wgrad_bf16 over n_seg recorded (h, dc) pairs of one shape in ONE launch: h_ptrs / dc_ptrs are DEVICE arrays of
+ * n_seg device pointers (bf16 [B*L][128] each); dwt += the sum over all pairs.  Same kernel, same deterministic
+ * split-K; workspace drk_conv_wgrad_bf16_multi_workspace_bytes(n_seg, B, L, taps) bytes. */
+long drk_conv_wgrad_bf16_multi_workspace_bytes(int n_seg, int B, int L, int taps);
+int drk_conv_wgrad_bf16_multi(const void* const* h_ptrs, const void* const* dc_ptrs, int n_seg, float* dwt, int B, int L,
+                              int taps, int dilation, void* workspace, long workspace_bytes, void* stream);
+/* out[i] += slabs[0][i] + slabs[1][i] + ... + slabs[n_slabs-1][i], in that order, i < n (n % 4 == 0, 16-byte aligned
+ * pointers, slab s at slabs + s * stride): the ordered second pass of the split reductions above. */
+int drk_slab_reduce(const float* slabs, int n_slabs, long stride, float* out, long n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -117,6 +117,127 @@ def test_layer_bf16_saves_and_input_gradient(dev, det_sd, layer):
     assert float((dh.cpu() - want_dh).abs().max()) <= 2e-5 * float(want_dh.abs().max()) + 1e-5
 
 
+@pytest.mark.parametrize('n_seg,B,L,taps,dil', [(3, 16, 200, 9, 1), (5, 3, 77, 9, 16), (50, 8, 200, 9, 64), (2, 5, 200, 1, 0),
+                                                (4, 1, 9, 9, 4), (7, 32, 200, 9, 4)])
+def test_wgrad_bf16_multi_kernel(dev, n_seg, B, L, taps, dil):
+    """drk_conv_wgrad_bf16_multi: the weight gradient summed over n_seg separately allocated (h, dc) pairs in one launch ==
+    the float64 sum of the per-pair gradients; segment ends inside a workgroup's tile run, ragged last tiles; bitwise
+    reproducible; and equal to within fp32 summation order to n_seg single calls."""
+    g = torch.Generator(device='cpu').manual_seed(n_seg * 131 + B * 7 + L)
+    hs = [torch.randn(B, L, 128, generator=g).to(torch.bfloat16).to(dev) for _ in range(n_seg)]
+    dcs = [(torch.randn(B, L, 128, generator=g) * torch.linspace(0.5, 2.0, 128)).to(torch.bfloat16).to(dev) for _ in range(n_seg)]
+    ref = sum(_wgrad_ref(h.float(), d.float(), taps, dil) for h, d in zip(hs, dcs))
+    hp = torch.tensor([h.data_ptr() for h in hs], dtype=torch.int64, device=dev)
+    dp = torch.tensor([d.data_ptr() for d in dcs], dtype=torch.int64, device=dev)
+    outs = []
+    for _ in range(2):
+        dwt = torch.full((taps, 128, 128), 0.25, device=dev)
+        ops.conv_wgrad_bf16_multi(hp, dp, n_seg, dwt, B, L, dil)
+        outs.append(dwt)
+    assert torch.equal(outs[0], outs[1])
+    got = outs[0].double().cpu() - 0.25
+    assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-4, (n_seg, B, L, taps, dil)
+    single = torch.zeros(taps, 128, 128, device=dev)
+    for h, d in zip(hs, dcs):
+        ops.conv_wgrad_bf16(h, d, single, dil)
+    assert float((single.double().cpu() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-4
+
+
+@pytest.mark.parametrize('B,L', [(3, 200), (128, 200), (1, 1), (2, 77)])
+def test_head_bwd_bf16_kernel(dev, B, L):
+    """drk_head_bwd_bf16: dc = bf16((dlogits x w2) * (y > 0)) bit-equal to drk_head_out_bwd + drk_gate_bf16, and the partial
+    slabs sum to dw2 / db0 / db2."""
+    g = torch.Generator(device='cpu').manual_seed(B + L)
+    dl = torch.randn(B, L, 5, generator=g).to(dev)
+    y = torch.relu(torch.randn(B, L, 128, generator=g)).to(dev)
+    w = torch.randn(5, 128, generator=g).to(dev)
+    W = int(AG._lib_slab())
+    nwg = (B * L + 127) // 128
+    P = torch.full((nwg, W + 8), 7.0, device=dev)
+    dc = torch.empty(B, L, 128, dtype=torch.bfloat16, device=dev)
+    ops.head_bwd_bf16(dl, y, w, dc, P, W + 8)
+    dy, dw, db = torch.empty_like(y), torch.zeros(5, 128, device=dev), torch.zeros(5, device=dev)
+    ops.head_out_bwd(dl, y, w, dy, dw, db)
+    cs = torch.zeros(128, device=dev)
+    want = ops.gate_bf16(dy, y=y, colsum=cs)
+    assert torch.equal(dc, want)
+    assert torch.equal(ops.head_bwd_bf16(dl, y, w, torch.empty_like(dc)), want)          # without partials
+    tot = P[:, :W].double().sum(0).cpu()
+    assert float((P[:, W:] - 7.0).abs().max()) == 0.0                                     # nothing beyond the slab is touched
+    dw_ref = torch.einsum('blv,blc->vc', dl.double().cpu(), y.double().cpu())
+    assert float((tot[:640].view(5, 128) - dw_ref).abs().max()) <= 1e-5 * float(dw_ref.abs().max()) + 1e-5
+    db0_ref = torch.where(y.cpu() > 0, (dl.double().cpu() @ w.double().cpu()), torch.zeros((), dtype=torch.float64)).sum((0, 1))
+    assert float((tot[640:768] - db0_ref).abs().max()) <= 1e-5 * float(db0_ref.abs().max()) + 1e-5
+    assert float((tot[768:773] - dl.double().sum((0, 1)).cpu()).abs().max()) <= 1e-5 * B * L
+    assert float(tot[773:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('B,L,layer,ln', [(3, 200, 0, True), (128, 200, 5, True), (3, 77, 9, True), (2, 200, 13, True),
+                                          (5, 200, 17, True), (2, 1024, 18, True), (3, 200, 20, False), (1, 9, 9, True)])
+def test_layer_bwd_bf16_kernel(dev, det_sd, B, L, layer, ln):
+    """drk_layer_bwd_bf16 — input gradient + LayerNorm backward + residual add + gate of the layer below + column-sum
+    partials in one launch — against float64 on the same bf16-rounded operands, per dilation, ragged row counts (B*L not a
+    multiple of the 128-row tile), in place (gout = gr); layer 20 = the head's 1x1 conv (ln = 0, no residual gradient)."""
+    m = drakes_amd.Diffusion(drakes_amd.default_config(length=L)).to(dev)
+    m.load_state_dict(det_sd)
+    bb = m.backbone
+    pk = bb.packed()
+    n = bb.num_layers
+    taps, d = (9, bb.dilation(layer)) if layer < n else (1, 0)
+    gen = torch.Generator(device='cpu').manual_seed(100 * layer + B)
+    dc = torch.randn(B, L, 128, generator=gen).to(torch.bfloat16)
+    if layer < n:
+        w = det_sd[f'backbone.convs.{layer}.weight'].to(torch.bfloat16).double()
+    else:
+        w = det_sd['backbone.final_conv.0.weight'].to(torch.bfloat16).double()
+    dh = F.conv_transpose1d(dc.double().permute(0, 2, 1), w, dilation=max(d, 1), padding=(taps // 2) * d).permute(0, 2, 1)
+    mask = (torch.rand(B, L, 128, generator=gen) > 0.45).to(torch.uint8)
+    M = B * L
+    kw = {}
+    if ln:
+        feat = torch.randn(B, L, 128, generator=gen) * 2
+        gr = torch.randn(B, L, 128, generator=gen)
+        tb = bb.time_bias(torch.zeros(1, device=dev))[0, layer].contiguous()
+        gamma = pk['ln_g'][layer]
+        xin = feat.double() + tb.double().cpu()
+        mean = xin.mean(-1)
+        rstd = (xin.var(-1, unbiased=False) + 1e-5).rsqrt()
+        xh = (xin - mean[..., None]) * rstd[..., None]
+        dyg = dh * gamma.double().cpu()
+        dx = rstd[..., None] * (dyg - dyg.mean(-1, keepdim=True) - xh * (dyg * xh).mean(-1, keepdim=True))
+        want = dx + gr.double()
+        sums = [(dh * xh).sum((0, 1)), dh.sum((0, 1)), dx.sum((0, 1))]
+        gout = gr.clone().to(dev)
+        kw = dict(feat=feat.to(dev), tbias=tb, gamma=gamma, mean=mean.float().reshape(M).to(dev),
+                  rstd=rstd.float().reshape(M).to(dev), gr=gout)
+    else:
+        want = dh
+        sums = [torch.zeros(128, dtype=torch.float64), torch.zeros(128, dtype=torch.float64), dh.sum((0, 1))]
+        gout = torch.empty(B, L, 128, device=dev)
+    gated = torch.where(mask.bool(), want, torch.zeros((), dtype=torch.float64))
+    sums.append(gated.sum((0, 1)))
+    nwg = (M + 127) // 128
+    W = 512 * 3
+    P = torch.full((nwg, W), 3.0, device=dev)
+    dc_next = torch.empty(B, L, 128, dtype=torch.bfloat16, device=dev)
+    ops.layer_bwd_bf16(dc.to(dev), fastpath._packed_T(bb)[9 * layer:], gout, next_mask=mask.to(dev), dc_next=dc_next,
+                       partials=P[0, 512:], part_stride=W, taps=taps, dilation=d, **kw)
+    scale = float(want.abs().max())
+    assert float((gout.double().cpu() - want).abs().max()) <= 2e-5 * scale + 1e-5
+    got_dc = dc_next.double().cpu()
+    assert float((got_dc - gated).abs().max()) <= 2 ** -8 * scale + 1e-5          # bf16 rounding of the gated gradient
+    assert torch.equal(got_dc == 0, (gated == 0) | (got_dc == 0)) and float(got_dc[~mask.bool()].abs().max()) == 0.0
+    assert float((P[:, :512] - 3.0).abs().max()) == 0.0 and float((P[:, 1024:] - 3.0).abs().max()) == 0.0
+    tot = P[:, 512:1024].double().sum(0).cpu().view(4, 128)
+    for k, ref in enumerate(sums):
+        assert float((tot[k] - ref).abs().max()) <= 2e-5 * max(float(ref.abs().max()), scale) + 1e-4, (k, B, L, layer)
+    # without the optional outputs (a frozen model's pass; layer 0: nothing below)
+    g2 = gr.clone().to(dev) if ln else torch.empty(B, L, 128, device=dev)
+    kw2 = dict(kw, gr=g2) if ln else {}
+    ops.layer_bwd_bf16(dc.to(dev), fastpath._packed_T(bb)[9 * layer:], g2, taps=taps, dilation=d, **kw2)
+    assert torch.equal(g2, gout)
+
+
 def _oracle_grads(sd, fn):
     sdg = {k: v.clone().requires_grad_(k != 'backbone.time_embedder.0.W') for k, v in sd.items()}
     fn(sdg).backward()
