@@ -62,6 +62,8 @@ SIGNATURES = {
     'drk_head_bwd_bf16': [_P, _P, _P, _P, _P, c_long, c_int, c_int, _P],
     'drk_conv_wgrad_bf16_multi': [_P, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, c_long, _P],
     'drk_slab_reduce': [_P, c_int, c_long, _P, c_long, _P],
+    'drk_denoiser_fwd_bf16': [_P] * 16 + [c_int, c_int, c_int, _P, _P],
+    'drk_denoiser_bwd_bf16': [_P] * 11 + [c_int] + [_P] * 9 + [c_int, c_int, c_int, _P, _P],
     'drk_sample_bf16': [_P, _P, _P, _P, _P, c_long, _P, _P, _P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, c_int,
                         c_uint64, c_uint64, c_int, _P],
 }
@@ -72,6 +74,7 @@ HOST_QUERIES = {
     'drk_gate_bf16_workspace_bytes': [],
     'drk_conv_wgrad_bf16_multi_workspace_bytes': [c_int, c_int, c_int, c_int],
     'drk_head_bwd_bf16_slab_floats': [],
+    'drk_denoiser_bwd_bf16_slab_floats': [c_int],
 }
 
 _lib = None

@@ -226,8 +226,9 @@ class GradSink:
         n = bb.num_layers
         self.n = n
         self.head_off = (n + 1) * 4 * C                  # layer slots 0..n-1, slot n = the head's input gradient launch
-        self.W = self.head_off + int(_lib_slab())        # + drk_head_bwd_bf16's slab
-        self.records = []                                # (B, L, hs, dcs)
+        self.W = self.head_off + int(_lib_slab())        # + drk_head_bwd_bf16's slab (= drk_denoiser_bwd_bf16_slab_floats(n))
+        self.records = []                                # (B, L, hs block [n+1,B,L,128], dcs block [n+1,B,L,128])
+        self.time = {}                                   # sigma key -> (sigma, temb, tbias): the time path runs once per sigma
         self.groups = {}                                 # sigma key -> (sigma, temb, acc [W])
         self.stem_dw = None
         self.stem_db = None
@@ -263,8 +264,9 @@ class GradSink:
             by_shape.setdefault((B, L), []).append((hs, dcs))
         for (B, L), recs in by_shape.items():
             K = len(recs)
-            ptrs = torch.tensor([[[r[w][i].data_ptr() for r in recs] for i in range(n + 1)] for w in (0, 1)], dtype=torch.int64,
-                                pin_memory=True).to(dev, non_blocking=True)
+            step = B * L * C * 2                       # bytes between the layers of a block
+            ptrs = torch.tensor([[[r[w].data_ptr() + i * step for r in recs] for i in range(n + 1)] for w in (0, 1)],
+                                dtype=torch.int64, pin_memory=True).to(dev, non_blocking=True)
             for i in range(n):
                 ops.conv_wgrad_bf16_multi(ptrs[0, i], ptrs[1, i], K, dwt[9 * i:9 * i + 9], B, L, bb.dilation(i))
             ops.conv_wgrad_bf16_multi(ptrs[0, n], ptrs[1, n], K, dwt[9 * n:], B, L, 0)
@@ -298,7 +300,7 @@ class GradSink:
         g['time_embedder.1.weight'], g['time_embedder.1.bias'] = d_lin_w, d_lin_b
         for i in range(n):
             g[f'time_layers.{i}.dense.weight'], g[f'time_layers.{i}.dense.bias'] = d_dense_w[i], d_dense_b[i]
-        self.records, self.groups, self.stem_dw, self.stem_db = [], {}, None, None
+        self.records, self.groups, self.time, self.stem_dw, self.stem_db = [], {}, {}, None, None
         return g
 
 
@@ -343,12 +345,10 @@ class _BackboneBf16Fn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, bb, seq, sigma, sink, *params):
-        ctx.sink, ctx.sigma_key = (sink if isinstance(sink, GradSink) else sink[0], None if isinstance(sink, GradSink) else sink[1]) \
-            if sink is not None else (None, None)
+        ctx.sink, ctx.sigma_key = (None, None) if sink is None else sink
         sink = ctx.sink
         from . import fastpath
         pk, st = bb.packed(), fastpath._packed(bb)
-        vec, wstream = st['vecs'], st['wstream']
         seq = seq.contiguous()
         B, L = seq.shape[0], seq.shape[1]
         n = bb.num_layers
@@ -356,10 +356,42 @@ class _BackboneBf16Fn(torch.autograd.Function):
         sigma = sigma.to(torch.float32).contiguous()
         nb = sigma.shape[0]
         assert nb in (1, B), 'sigma: one value per row or one shared value'
-        temb = ops.time_embed_fwd(sigma, pk['four_W'], pk['temb_w'], pk['temb_b'])
-        tbias = ops.time_bias_fwd(temb, pk['dense_w'], pk['dense_b'])
+        hit = sink.time.get(ctx.sigma_key) if (sink is not None and ctx.sigma_key is not None) else None
+        if hit is not None:                         # the time path of this sigma ran earlier in the chain (same weights)
+            sigma, temb, tbias = hit
+        else:
+            temb = ops.time_embed_fwd(sigma, pk['four_W'], pk['temb_w'], pk['temb_b'])
+            tbias = ops.time_bias_fwd(temb, pk['dense_w'], pk['dense_b'])
+            if sink is not None and ctx.sigma_key is not None:
+                sink.time[ctx.sigma_key] = (sigma, temb, tbias)
         tb_stride = tbias.stride(0) if nb == B and B > 1 else 0
-        assert sink is None or not tb_stride, 'a gradient chain shares one sigma per forward'
+        ctx.bb, ctx.pk, ctx.seq, ctx.sigma, ctx.temb, ctx.tbias, ctx.tb_stride = bb, pk, seq, sigma, temb, tbias, tb_stride
+        ctx.names = [k for k, _ in bb.named_parameters()]
+        if tb_stride:
+            assert sink is None, 'a gradient chain shares one sigma per forward'
+            return _BackboneBf16Fn._forward_rows(ctx, st)
+        M = B * L
+        feats = torch.empty(n + 1, B, L, C, dtype=torch.float32, device=dev)
+        hs = torch.empty(n + 1, B, L, C, dtype=torch.bfloat16, device=dev)
+        masks = torch.empty(n, B, L, C, dtype=torch.uint8, device=dev)
+        stats = torch.empty(2, n, M, dtype=torch.float32, device=dev)
+        y = torch.empty(B, L, C, dtype=torch.float32, device=dev)
+        logits = torch.empty(B, L, V, dtype=torch.float32, device=dev)
+        ops.denoiser_fwd_bf16(seq, pk, st, tbias[0], feats, hs, masks, stats[0], stats[1], y, logits)
+        ctx.st = st
+        ctx.feats, ctx.hs, ctx.means, ctx.rstds, ctx.masks, ctx.y = feats, hs, stats[0], stats[1], masks, y
+        if _BackboneBf16Fn.gate_log is not None:   # tests: the ReLU gates this forward took (see oracle/bf16_emulation.py)
+            _BackboneBf16Fn.gate_log.append((masks, y, feats[0]))
+        return logits
+
+    @staticmethod
+    def _forward_rows(ctx, st):
+        """A time bias per batch row (per-row sigma): the per-launch sequence of round 2."""
+        bb, pk, seq, tbias, tb_stride = ctx.bb, ctx.pk, ctx.seq, ctx.tbias, ctx.tb_stride
+        vec, wstream = st['vecs'], st['wstream']
+        B, L = seq.shape[0], seq.shape[1]
+        n = bb.num_layers
+        dev = seq.device
         f32 = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
         b16 = lambda: torch.empty(B, L, C, dtype=torch.bfloat16, device=dev)
         feats = [ops.stem_fwd(seq, pk['stem_w'], pk['stem_b'])]
@@ -380,10 +412,8 @@ class _BackboneBf16Fn(torch.autograd.Function):
         # hs[n] = bf16(feat_n): final_conv.0 (1x1) + ReLU on the same kernel, then the exact-fp32 128 -> 5 conv
         y = ops.layer_bf16(hs[n], wstream[9 * n:], f32(B, L, C), bias=vec[3 * n + 1], taps=1, dilation=0, relu=True)
         logits = ops.head_out_fwd(y, pk['head2_w'], pk['head2_b'])
-        ctx.bb, ctx.pk, ctx.seq, ctx.sigma, ctx.temb, ctx.tbias, ctx.tb_stride = bb, pk, seq, sigma, temb, tbias, tb_stride
         ctx.feats, ctx.hs, ctx.means, ctx.rstds, ctx.masks, ctx.y = feats, hs, means, rstds, masks, y
-        ctx.names = [k for k, _ in bb.named_parameters()]
-        if _BackboneBf16Fn.gate_log is not None:   # tests: the ReLU gates this forward took (see oracle/bf16_emulation.py)
+        if _BackboneBf16Fn.gate_log is not None:
             _BackboneBf16Fn.gate_log.append((masks, y, feats[0]))
         return logits
 
@@ -394,50 +424,26 @@ class _BackboneBf16Fn(torch.autograd.Function):
         if ctx.tb_stride:
             return _BackboneBf16Fn._backward_unfused(ctx, dlogits)
         from . import fastpath
-        bb, pk, seq = ctx.bb, ctx.pk, ctx.seq
-        feats, hs, means, rstds, masks, y = ctx.feats, ctx.hs, ctx.means, ctx.rstds, ctx.masks, ctx.y
+        bb, pk, st, seq = ctx.bb, ctx.pk, ctx.st, ctx.seq
         B, L = seq.shape[0], seq.shape[1]
         M, n = B * L, bb.num_layers
         dev = dlogits.device
         dlogits = dlogits.contiguous()
         want_w = any(ctx.needs_input_grad[4:])     # a frozen model (the KL reference model) only passes the input gradient on
-        wT = fastpath._packed_T(bb)
         sink = ctx.sink if ctx.sink is not None else (GradSink(bb) if want_w else None)
-        b16 = lambda: torch.empty(B, L, C, dtype=torch.bfloat16, device=dev)
-        P, W = None, 0
+        dcs = torch.empty(n + 1 if want_w else 2, B, L, C, dtype=torch.bfloat16, device=dev)
+        gr = torch.empty(B, L, C, dtype=torch.float32, device=dev)      # the residual-gradient stream, updated in place
+        dseq = torch.empty_like(seq) if (seq.dtype != torch.int64 and ctx.needs_input_grad[1]) else None
+        kw = {}
         if want_w:
-            W, nwg = sink.W, (M + 127) // 128
-            P = ops.workspace(nwg * W * 4, dev)      # [workgroup][W]: every slot is written by exactly one launch below
-        slot = lambda i: P[4 * C * i:] if want_w else None
-        # head: 128 -> 5 conv and final_conv.0's ReLU in one pass, then final_conv.0's input gradient with the gate of the
-        # last residual layer in its epilogue
-        dcs = [None] * (n + 1)
-        dcs[n] = ops.head_bwd_bf16(dlogits, y, pk['head2_w'], b16(), P[sink.head_off:] if want_w else None, W)
-        gr = torch.empty_like(y)                      # the residual-gradient stream, updated in place layer by layer
-        pong = [b16(), b16()] if not want_w else None
-        nxt = lambda i: b16() if want_w else pong[i & 1]
-        dcs[n - 1] = nxt(n - 1)
-        ops.layer_bwd_bf16(dcs[n], wT[9 * n:], gr, next_mask=masks[n - 1], dc_next=dcs[n - 1], partials=slot(n), part_stride=W,
-                           taps=1, dilation=0)
-        for i in reversed(range(n)):
-            if i:
-                dcs[i - 1] = nxt(i - 1)
-            ops.layer_bwd_bf16(dcs[i], wT[9 * i:], gr, feat=feats[i], tbias=ctx.tbias[0, i], gamma=pk['ln_g'][i], mean=means[i],
-                               rstd=rstds[i], gr=gr, next_mask=masks[i - 1] if i else None, dc_next=dcs[i - 1] if i else None,
-                               partials=slot(i), part_stride=W, taps=9, dilation=bb.dilation(i))
-        # stem: the fp32 kernels
-        dpre = ops.relu_bwd(gr, feats[0], out=gr)
-        dseq = torch.empty_like(seq) if seq.dtype != torch.int64 else None
-        if want_w:
-            ops.slab_reduce(P, nwg, W, sink.group(ctx.sigma_key, ctx.sigma, ctx.temb), W)
+            P = ops.workspace((M + 127) // 128 * sink.W * 4, dev)      # [workgroup][W]: every slot written by one launch
             dw_t, db = sink.stem(dev)
-            ops.colsum128(dpre, 1, M, db)
-            ops.stem_bwd(dpre, seq, pk['stem_w'], dw_t, dseq)
-            sink.records.append((B, L, hs, dcs))
-        elif dseq is not None:
-            ops.stem_bwd(dpre, seq, pk['stem_w'], torch.zeros(9, V, C, dtype=torch.float32, device=dev), dseq)
+            kw = dict(partials=P, acc=sink.group(ctx.sigma_key, ctx.sigma, ctx.temb), stem_dw=dw_t, stem_db=db)
+        ops.denoiser_bwd_bf16(dlogits, seq, pk, st, fastpath._packed_T(bb), ctx.tbias[0], ctx.feats, ctx.masks, ctx.means,
+                              ctx.rstds, ctx.y, dcs, gr, dx=dseq, **kw)
+        if want_w:
+            sink.records.append((B, L, ctx.hs, dcs))
         ctx.feats = ctx.hs = ctx.masks = ctx.means = ctx.rstds = ctx.y = None
-        dseq = dseq if ctx.needs_input_grad[1] else None
         if ctx.sink is not None or not want_w:        # the chain's _ChainFn hands the parameters their gradients
             return (None, dseq, None, None) + (None,) * len(ctx.needs_input_grad[4:])
         g = sink.flush()

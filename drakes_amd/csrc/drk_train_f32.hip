@@ -963,11 +963,13 @@ extern "C" int drk_head_out_bwd(const float* dlogits, const float* y, const floa
 extern "C" int drk_stem_bwd(const float* dpre, const int64_t* x, const float* x_soft, const float* w_t, float* dw_t,
                             float* dx, int B, int L, void* stream) {
   DRK_SHAPE_GUARD("drk_stem_bwd");
-  ARGCHECK(dpre && (x || x_soft) && w_t && dw_t, "drk_stem_bwd");
+  ARGCHECK(dpre && (x || x_soft) && w_t && (dw_t || dx), "drk_stem_bwd");
   const long M = (long)B * L;
-  hipLaunchKernelGGL(k_stem_wgrad, dim3((unsigned)((M + 63) / 64)), dim3(256), 0, (hipStream_t)stream, dpre, x, x_soft,
-                     dw_t, M, L);
-  DRK_CHECK_LAUNCH();
+  if (dw_t) {   // (NULL: a frozen model passes only the input gradient on)
+    hipLaunchKernelGGL(k_stem_wgrad, dim3((unsigned)((M + 63) / 64)), dim3(256), 0, (hipStream_t)stream, dpre, x, x_soft,
+                       dw_t, M, L);
+    DRK_CHECK_LAUNCH();
+  }
   if (dx) {
     hipLaunchKernelGGL(k_stem_dgrad, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, dpre, w_t, dx, M, L);
     DRK_CHECK_LAUNCH();

@@ -432,6 +432,31 @@ def conv_wgrad_bf16_multi(h_ptrs, dc_ptrs, n_seg, dwt, B, L, dilation, ws=None):
               dilation, _f(ws, 'workspace'), ws.numel() * 4, _stream())
 
 
+def denoiser_fwd_bf16(seq, pk, st, tbias, feats, hs, masks, means, rstds, y, logits):
+    """drk_denoiser_fwd_bf16: the whole differentiable forward in one native call.  pk = CNNModel.packed(), st =
+    fastpath._packed(bb); tbias [n_layers,128] (one row for the batch); the outputs are whole blocks (see the header)."""
+    B, L = seq.shape[0], seq.shape[1]
+    tok = seq.dtype == torch.int64
+    _lib.call('drk_denoiser_fwd_bf16', _i(seq, 'x') if tok else None, None if tok else _f(seq, 'x_soft'), _f(pk['stem_w'], 'stem_w'),
+              _f(pk['stem_b'], 'stem_b'), _b16(st['wstream'], 'wstream'), _f(st['vecs'], 'vecs'), _f(tbias, 'tbias'),
+              _f(pk['head2_w'], 'head2_w'), _f(pk['head2_b'], 'head2_b'), _f(feats, 'feats'), _b16(hs, 'hs'),
+              _dev_ptr(masks, torch.uint8, 'masks'), _f(means, 'means'), _f(rstds, 'rstds'), _f(y, 'y'), _f(logits, 'logits'),
+              B, L, st['n_layers'], st['dil'], _stream())
+    return logits
+
+
+def denoiser_bwd_bf16(dlogits, seq, pk, st, wstream_t, tbias, feats, masks, means, rstds, y, dcs, gr, partials=None, acc=None,
+                      stem_dw=None, stem_db=None, dx=None):
+    """drk_denoiser_bwd_bf16: the whole backward except weight gradients and the time path, in one native call."""
+    B, L = seq.shape[0], seq.shape[1]
+    tok = seq.dtype == torch.int64
+    _lib.call('drk_denoiser_bwd_bf16', _f(dlogits, 'dlogits'), _f(y, 'y'), _f(pk['head2_w'], 'head2_w'), _b16(wstream_t, 'wstream_t'),
+              _f(st['vecs'], 'vecs'), _f(tbias, 'tbias'), _f(feats, 'feats'), _dev_ptr(masks, torch.uint8, 'masks'),
+              _f(means, 'means'), _f(rstds, 'rstds'), _b16(dcs, 'dcs'), dcs.shape[0], _f(gr, 'gr'), _f(partials, 'partials'),
+              _f(acc, 'acc'), _i(seq, 'x') if tok else None, None if tok else _f(seq, 'x_soft'), _f(pk['stem_w'], 'stem_w'),
+              _f(stem_dw, 'stem_dw'), _f(stem_db, 'stem_db'), _f(dx, 'dx'), B, L, st['n_layers'], st['dil'], _stream())
+
+
 def slab_reduce(slabs, n_slabs, stride, out, n):
     """out[:n] += slabs[0][:n] + slabs[1][:n] + ... in order (slab s at element s * stride of `slabs`)."""
     _lib.call('drk_slab_reduce', _raw(slabs), n_slabs, stride, _raw(out), n, _stream())

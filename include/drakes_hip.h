@@ -345,6 +345,36 @@ int drk_conv_wgrad_bf16_multi(const void* const* h_ptrs, const void* const* dc_p
  * pointers, slab s at slabs + s * stride): the ordered second pass of the split reductions above. */
 int drk_slab_reduce(const float* slabs, int n_slabs, long stride, float* out, long n, void* stream);
 
+/* The whole differentiable denoiser forward (models/dnaconv.py:74-110 on the bf16 layer kernels) as ONE call: the launch
+ * sequence drk_stem_fwd, drk_ln_fwd_bf16, n_layers x drk_layer_bf16 (ReLU gates and LayerNorm statistics kept),
+ * drk_layer_bf16 (final_conv.0), drk_head_out_fwd, walked in native code — at fine-tune batch sizes the launches are
+ * shorter than a Python-side sequence's host work.  Exactly one of x (int64 [B*L]) / x_soft (float32 [B*L][5]);
+ * stem_w_t [9][5][128]; wstream, vecs: drakes_amd/fastpath.py::pack_stream; tbias [n_layers][128], shared by the batch;
+ * dilations: HOST array [n_layers].  Outputs, one block each: feats float32 [n_layers+1][B*L][128] (residual snapshots),
+ * hs bf16 [n_layers+1][B*L][128] (LayerNorm outputs; the last = bf16 of the last residual state), masks uint8
+ * [n_layers][B*L][128], means / rstds float32 [n_layers][B*L], y float32 [B*L][128] (final_conv.0's ReLU output),
+ * logits float32 [B*L][5]. */
+int drk_denoiser_fwd_bf16(const int64_t* x, const float* x_soft, const float* stem_w_t, const float* stem_b,
+                          const void* wstream, const float* vecs, const float* tbias, const float* head2_w,
+                          const float* head2_b, float* feats, void* hs, unsigned char* masks, float* means, float* rstds,
+                          float* y, float* logits, int B, int L, int n_layers, const int* dilations, void* stream);
+/* Its backward except the convolutions' weight gradients and the time path (torch autograd over models/dnaconv.py:74-110
+ * in the reference): drk_head_bwd_bf16, (n_layers + 1) x drk_layer_bwd_bf16, drk_relu_bwd, drk_slab_reduce,
+ * drk_colsum128, drk_stem_bwd in one call.  wstream_t: drakes_amd/fastpath.py::pack_stream_T; feats, masks, means, rstds,
+ * y: the forward's blocks.  dcs bf16 [dcs_slots][B*L][128]: dcs_slots = n_layers + 1 keeps every convolution's gated
+ * output gradient (slot i pairs with hs[i] in drk_conv_wgrad_bf16_multi; slot n_layers = final_conv.0), dcs_slots = 2
+ * ping-pongs (a frozen model; partials must be NULL).  gr: float32 [B*L][128] work buffer.  partials: ceil(B*L / 128)
+ * slabs of drk_denoiser_bwd_bf16_slab_floats(n_layers) floats — slot i < n_layers: layer i's [4][128] of
+ * drk_layer_bwd_bf16, slot n_layers: final_conv.0's input-gradient launch, then drk_head_bwd_bf16's slab — summed in
+ * order into acc (+=, same length); stem_dw [9][5][128], stem_db [128] (+=, atomics); dx float32 [B*L][5] (x_soft only,
+ * may be NULL).  partials, acc, stem_dw, stem_db: all or none. */
+long drk_denoiser_bwd_bf16_slab_floats(int n_layers);
+int drk_denoiser_bwd_bf16(const float* dlogits, const float* y, const float* head2_w, const void* wstream_t,
+                          const float* vecs, const float* tbias, const float* feats, const unsigned char* masks,
+                          const float* means, const float* rstds, void* dcs, int dcs_slots, float* gr, float* partials,
+                          float* acc, const int64_t* x, const float* x_soft, const float* stem_w_t, float* stem_dw,
+                          float* stem_db, float* dx, int B, int L, int n_layers, const int* dilations, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
