@@ -86,12 +86,13 @@ class _BackboneFn(torch.autograd.Function):
     the whole batch (the sampler's case: all rows sit at the same time, :527-528)."""
 
     @staticmethod
-    def forward(ctx, bb, seq, sigma, flat_mode, *params):
+    def forward(ctx, bb, seq, sigma, mode, *params):
+        flat_mode, use_x3 = mode
         ctx.flat_mode = bool(flat_mode)
         pk = bb.packed()
-        # train_dtype 'bf16x3': the convolutions (forward and input gradient) at fp32 grade on the bf16 matrix cores
+        # 'bf16x3': the convolutions (forward and input gradient) at fp32 grade on the bf16 matrix cores
         # (drk_conv_fwd_x3); weight gradients and everything else stay on the exact-fp32 kernels
-        x3 = bb.packed_x3() if getattr(bb, 'train_dtype', 'fp32') == 'bf16x3' else None
+        x3 = bb.packed_x3() if use_x3 else None
         conv = (lambda hh, i, *a, **k: ops.conv_fwd_x3(hh, x3['conv_w3'][i], *a, **k)) if x3 else \
                (lambda hh, i, *a, **k: ops.conv_fwd_f32(hh, pk['conv_w'][i], *a, **k))
         seq = seq.contiguous()
@@ -524,7 +525,7 @@ class _BackboneBf16Fn(torch.autograd.Function):
 
 def backbone_with_grad(bb, seq, sigma, dtype='fp32', flat=None, sink=None, sigma_key=None):
     """dtype 'bf16': the bf16-MFMA layer kernels (gradients within the bf16 bar); 'fp32': the exact-fp32 kernels;
-    'bf16x3': those with the convolutions at fp32 grade on the bf16 matrix cores (read from bb.train_dtype).
+    'bf16x3': those with the convolutions (forward and input gradient) at fp32 grade on the bf16 matrix cores.
     flat: flat_params(bb), built once by a caller that runs many forwards per backward pass (see there); on the bf16 path
     (sink, flat) = grad_chain(bb) instead, and sigma_key = sigma's value as a Python number when the caller knows it."""
     if dtype is True:
@@ -533,9 +534,10 @@ def backbone_with_grad(bb, seq, sigma, dtype='fp32', flat=None, sink=None, sigma
         if sink is not None:
             return _BackboneBf16Fn.apply(bb, seq, sigma, (sink, sigma_key), flat)
         return _BackboneBf16Fn.apply(bb, seq, sigma, None, *bb.parameters())
+    x3 = dtype == 'bf16x3'
     if flat is not None:
-        return _BackboneFn.apply(bb, seq, sigma, True, flat)
-    return _BackboneFn.apply(bb, seq, sigma, False, *bb.parameters())
+        return _BackboneFn.apply(bb, seq, sigma, (True, x3), flat)
+    return _BackboneFn.apply(bb, seq, sigma, (False, x3), *bb.parameters())
 
 
 class _SubsFn(torch.autograd.Function):

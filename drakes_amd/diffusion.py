@@ -14,7 +14,8 @@ Differences a caller can see, all additive:
     index of row 0 (data-parallel shards draw the noise of their own rows).
   * `hip_dtype` ('fp32' | 'bf16x3' | 'bf16') selects the exact-fp32 kernels (the parity path), the same step loop with
     the convolutions at fp32 grade on the bf16 matrix cores (three bf16 planes per operand: logits within ~1e-5 of the
-    exact path's, ~3x its speed; gradient-free paths only), or the bf16-MFMA fast path (one launch per `_sample`);
+    exact path's, ~3x its speed; under autograd the forward and input-gradient convolutions use it, weight gradients stay
+    on the f32 MFMA), or the bf16-MFMA fast path (one launch per `_sample`; differentiable steps on the bf16 layer kernels);
     `hip_graph = True` replays the fp32 step loop from a captured hipGraph.
 """
 import torch
@@ -97,7 +98,10 @@ class Diffusion(nn.Module):
 
     def forward(self, x, sigma):
         """Returns log score — reference :266-275."""
-        sigma = self._process_sigma(sigma)
+        uniform = getattr(sigma, '_drk_uniform', None)     # set by this package's samplers on the condt tensors they record:
+        sigma = self._process_sigma(sigma)                 # every row holds this one value (known without a device read)
+        if not self.time_conditioning or uniform is not None:
+            sigma = sigma[:1]                              # one time bias for the batch: same values, one row of work
         self.backbone.train_dtype = self._soft_dtype()
         logits = self.backbone(x, sigma)
         return self._subs_parameterization(logits=logits, xt=x)

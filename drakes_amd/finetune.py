@@ -84,6 +84,7 @@ def sample_finetune_gradient(model, num_steps=None, eps=1e-5, eval_sp_size=None,
                 xi = traj[i].to(torch.int64)
                 last_x_list.append(F.one_hot(xi, num_classes=model.vocab_size).to(torch.float32))
                 condt_list.append(torch.full((batch,), table[i][1], dtype=torch.float32, device=dev))
+                condt_list[-1]._drk_uniform = float(table[i][1])
                 move_chance_t_list.append(torch.full((batch, 1, 1), table[i][2], dtype=torch.float32, device=dev))
                 copy_flag_list.append((xi != model.mask_index).to(torch.int64).unsqueeze(-1))
         first = n_hard
@@ -91,6 +92,7 @@ def sample_finetune_gradient(model, num_steps=None, eps=1e-5, eval_sp_size=None,
         _, sigma_t, mc_t, mc_s = table[i]
         u = uniforms(i) if uniforms is not None else None
         condt = torch.full((batch,), sigma_t, dtype=torch.float32, device=dev)
+        condt._drk_uniform = float(sigma_t)        # Diffusion.forward: every row holds this value
         mct = torch.full((batch, 1, 1), mc_t, dtype=torch.float32, device=dev)
         if i < num_steps - trunc:                                           # hard step, no graph (:615-619)
             with torch.no_grad():

@@ -229,4 +229,6 @@ class CNNModel(nn.Module):
             from ..autograd import backbone_with_grad
             return backbone_with_grad(self, seq.contiguous(), t.to(torch.float32), getattr(self, 'train_dtype', 'fp32'))
         tbias = self.time_bias(t.to(torch.float32))
-        return self.forward_f32(seq.contiguous(), tbias, tbias.stride(0))
+        if t.shape[0] not in (1, seq.shape[0]):
+            raise ValueError(f't: one value per batch row or one shared value (got {t.shape[0]} for batch {seq.shape[0]})')
+        return self.forward_f32(seq.contiguous(), tbias, tbias.stride(0) if t.shape[0] == seq.shape[0] and t.shape[0] > 1 else 0)
