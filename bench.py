@@ -98,27 +98,48 @@ def _free_port():
 
 def spawn_ranks(n):
     """Starts one child per rank (what torch.distributed.run would do), relays rank 0's stdout, returns the exit code.
-    Runs before this process has touched the GPU: the parent never initialises HIP."""
+    Runs before this process has touched the GPU: the parent never initialises HIP.  Every child is polled: the first
+    non-zero exit, or the wall-clock limit (DRK_BENCH_TIMEOUT seconds, default 1500), ends the others (our own children,
+    by PID) instead of leaving rank 0 in a rendezvous until the process-group timeout."""
+    import tempfile
     port = _free_port()
+    limit = float(os.environ.get('DRK_BENCH_TIMEOUT', '1500'))
     procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0', PYTHONUNBUFFERED='1')
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
     rc = 0
-    try:
-        out0 = procs[0].communicate()[0].decode(errors='replace')
-        for p in procs:
-            p.wait()
-            rc = rc or p.returncode
-    finally:
-        for p in procs:                               # our own children, by PID
-            if p.poll() is None:
-                p.kill()
-                rc = rc or 1
-    sys.stdout.write(out0)
-    sys.stdout.flush()
+    with tempfile.TemporaryFile() as out0, tempfile.TemporaryFile() as err_rest:
+        try:
+            for r in range(n):
+                env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                           MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0', PYTHONUNBUFFERED='1')
+                procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                              stdout=out0 if r == 0 else err_rest))
+            t0 = time.monotonic()
+            while True:
+                codes = [p.poll() for p in procs]
+                bad = [c for c in codes if c not in (None, 0)]
+                if bad:
+                    rc = bad[0]
+                    break
+                if all(c == 0 for c in codes):
+                    break
+                if time.monotonic() - t0 > limit:
+                    rc = 124
+                    print(f'bench.py: ranks still running after {limit:.0f} s', file=sys.stderr)
+                    break
+                time.sleep(0.1)
+        finally:
+            for p in procs:                               # our own children, by PID
+                if p.poll() is None:
+                    p.kill()
+                    rc = rc or 1
+            for p in procs:
+                p.wait()
+        out0.seek(0)
+        sys.stdout.write(out0.read().decode(errors='replace'))
+        sys.stdout.flush()
+        if rc:
+            err_rest.seek(0)
+            sys.stderr.write(err_rest.read().decode(errors='replace')[-2000:])
     if rc:
         print(f'bench.py: a rank exited with {rc}', file=sys.stderr)
     return rc
@@ -230,7 +251,7 @@ def secondary_fp32(model, B=1024, dtype='fp32'):
     same workload, in the same run: one warm-up call, one timed call."""
     model.hip_dtype = dtype
     try:
-        model._sample(eval_sp_size=64, seed=1)
+        model._sample(eval_sp_size=B, seed=1)         # warm-up at the timed shape: work buffers exist before the clock starts
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         model._sample(eval_sp_size=B, seed=2)
@@ -305,37 +326,72 @@ def workload_long(args, rank, world, dev, barrier):
     return out, elapsed
 
 
-def workload_finetune(args, rank, world, dev, barrier):
-    """configs[2]: `_sample_finetune_gradient` (78 hard + 50 soft steps) + backward of a synthetic linear reward."""
+def workload_finetune(args, rank, world, dev, barrier, backend):
+    """configs[2] per GPU and configs[3] across GPUs.  One step = one data-parallel fine-tune micro-step of the reference's
+    loop (finetune_reward_bp.py:40-43, 83-93) with a synthetic linear reward: `_sample_finetune_gradient` (78 hard + 50
+    soft steps) on this rank's batch shard, backward, ONE all-reduce of the flat gradient bucket (drakes_amd.dp.GradBucket,
+    13.3 MB) -> mean -> clip_grad_norm_ -> Adam.step.  At N = 1 the all-reduce still runs, through an RCCL group of one."""
+    import torch.distributed as dist
     import drakes_amd
+    from drakes_amd import dp
     B = args.batch if args.batch != 1024 else 128
     cfg = drakes_amd.default_config(length=L, steps=NUM_STEPS, truncate_steps=50)
     m = drakes_amd.Diffusion(cfg).to(dev).train()
     m.hip_dtype = args.dtype
     rw = torch.randn(B, 4, L, device=dev)
+    optim = torch.optim.Adam(m.parameters(), lr=1e-4)
+    bucket = dp.GradBucket(m)
+    timed = backend == 'nccl' and dist.is_initialized()
+    ar_events, ar_host = [], []
 
-    def one(k):
-        m.zero_grad(set_to_none=True)
+    def one(k, record):
+        bucket.zero_()
         out = m._sample_finetune_gradient(eval_sp_size=B, seed=100 + k, sample_offset=rank * B)[0]
         (-(out.permute(0, 2, 1) * rw).sum((1, 2)).mean()).backward()
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            bucket.allreduce_mean_(force=True)
+            e1.record()
+            if record:
+                ar_events.append((e0, e1))
+        else:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            bucket.allreduce_mean_(force=True)
+            torch.cuda.synchronize()
+            if record:
+                ar_host.append(time.perf_counter() - t0)
+        bucket.clip_grad_norm_(1.0)
+        optim.step()
 
     for k in range(args.warmup):
-        one(k)
+        one(k, False)
     barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        one(args.warmup + k)
+        one(args.warmup + k, True)
     barrier()
     elapsed = time.perf_counter() - t0
+    ar_us = [a.elapsed_time(b) * 1e3 for a, b in ar_events] if timed else [t * 1e6 for t in ar_host]
     # dense FLOPs: 128 forwards + 50 x (input-gradient + weight-gradient convs) = 128 + 100 forward-equivalents
     flop = B * L * FLOP_PER_POS_FWD * (NUM_STEPS + 2 * 50)
     per = elapsed / args.steps
-    out = {'metric': 'fine-tune sampling passes/sec (configs[2]: _sample_finetune_gradient K=50 + backward, batch 128)',
+    from drakes_amd import _lib
+    cfgname = 'configs[2]' if world == 1 else 'configs[3]'
+    out = {'metric': 'fine-tune 128-sequence shard passes/sec, all GPUs (configs[2] per GPU, configs[3] across GPUs: '
+                     '_sample_finetune_gradient K=50 + backward + gradient all-reduce + clip + Adam per pass)',
            'value': world * args.steps / elapsed, 'unit': 'passes/sec', 'dtype': 'bf16' if args.dtype == 'bf16' else 'f32',
            'data': 'synthetic (random-init weights, linear reward, in-kernel Philox noise)',
-           'config': {'workload': f'configs[2]: batch {B} per GPU, L=200, 128 steps, K=50', 'global_batch': world * B,
-                      'seq_len': L, 'parallelism': f'dp{world}'},
-           'seconds_per_pass': per, 'peak_mem_GiB': torch.cuda.max_memory_allocated() / 2 ** 30,
+           'config': {'workload': f'{cfgname}: batch {B} per GPU, L=200, 128 steps, K=50, one optimizer step per pass',
+                      'global_batch': world * B, 'seq_len': L,
+                      'parallelism': f'dp{world} (batch shards; one {bucket.flat.numel() * 4 / 1e6:.1f} MB gradient all-reduce per step)'},
+           'seconds_per_pass': per, 'sequences_per_sec': world * B / per, 'peak_mem_GiB': torch.cuda.max_memory_allocated() / 2 ** 30,
+           'drk_version': _lib.load().drk_version(),
+           'allreduce_in_loop': {'backend': backend if dist.is_initialized() else None, 'bytes': bucket.flat.numel() * 4,
+                                 'us_median': _median(ar_us) if ar_us else None, 'us_all': [round(u, 1) for u in ar_us],
+                                 'timed_by': 'HIP events on the stream' if timed else 'host clock around a synchronised call '
+                                             '(gloo staged through the host: ranks share a GPU)'},
            'roofline': {'bound': 'mfma', 'kernel': 'whole pass', 'achieved': flop / per / 1e12, 'peak': PEAK[args.dtype],
                         'unit': 'TFLOP/s', 'frac': flop / per / 1e12 / PEAK[args.dtype], 'traffic': None}}
     return out, elapsed
@@ -368,8 +424,8 @@ def main():
     dev = torch.device('cuda', local_rank)
     backend = os.environ.get('DRK_BENCH_BACKEND') or ('gloo' if shared_device else 'nccl')
     collective = {'backend': backend, 'world': world}
+    import torch.distributed as dist
     if world > 1:
-        import torch.distributed as dist
         with _stdout_to_stderr():
             if backend == 'nccl':
                 dist.init_process_group('nccl', device_id=dev)        # RCCL over xGMI
@@ -400,7 +456,18 @@ def main():
     elif args.workload == 'long':
         out, elapsed = workload_long(args, rank, world, dev, barrier)
     else:
-        out, elapsed = workload_finetune(args, rank, world, dev, barrier)
+        if world == 1:                       # the step's all-reduce runs through an RCCL group of one
+            try:
+                with _stdout_to_stderr():
+                    dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{_free_port()}', rank=0, world_size=1,
+                                            device_id=dev)
+                    one = torch.ones(1, device=dev)
+                    dist.all_reduce(one)
+                    torch.cuda.synchronize()
+                collective['ranks_seen'] = int(one.item())
+            except Exception as e:
+                collective = {'backend': None, 'world': 1, 'error': f'{type(e).__name__}: {e}'[:300]}
+        out, elapsed = workload_finetune(args, rank, world, dev, barrier, backend)
     if world > 1:
         t = torch.tensor([elapsed], device=dev if backend == 'nccl' else 'cpu', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -412,8 +479,12 @@ def main():
                 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
                 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None}
         line.update(out)
+        if 'drk_version' not in line:
+            from drakes_amd import _lib
+            line['drk_version'] = _lib.load().drk_version()
         if world == 1:
-            collective = _rccl_world1_probe(dev)
+            if args.workload != 'finetune':
+                collective = _rccl_world1_probe(dev)
             if args.workload == 'sample' and args.dtype == 'bf16' and not args.no_secondary:
                 line['secondary'] = {'fp32_token_exact_seq_per_s': secondary_fp32(model),
                                      'bf16x3_fp32_grade_seq_per_s': secondary_fp32(model, dtype='bf16x3'),
@@ -425,9 +496,10 @@ def main():
                 line['cpu_baseline'] = cpu_baseline()
         line['collective'] = collective
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or dist.is_initialized():
         with _stdout_to_stderr():
-            dist.barrier()
+            if world > 1:
+                dist.barrier()
             dist.destroy_process_group()
 
 
