@@ -21,10 +21,32 @@ def test_world2_matches_world1_on_gpu(tmp_path, hip_dtype):
         assert r['views_ok']
     assert torch.equal(torch.cat([r['mine'] for r in two]), one['tokens'])
     assert torch.equal(two[0]['flat'], two[1]['flat'])
-    # gradients: fp32 atomics in the weight-gradient kernels make the summation order run-dependent
+    # Gradients.  The convolution weights (99 % of the bucket) come from deterministic split-K reductions: a repeated
+    # world-2 run gives the same bits, and world 2 differs from world 1 only by where the sum over rows is cut (two ranks
+    # of 2 rows, then the mean, against one pass over 4 rows): fp32 summation order, 1e-6 of the largest gradient.  The
+    # small vectors (LayerNorm affine, biases, time path, stem) still gather per-workgroup sums with fp32 atomics on the
+    # fp32 path, so their order is run-dependent: 1e-5.
+    import drakes_amd
+    from drakes_amd import dp
+    m = drakes_amd.Diffusion(drakes_amd.default_config(length=200, steps=16, num_cnn_stacks=4, truncate_steps=4))
+    conv = torch.zeros(one['flat'].numel(), dtype=torch.bool)
+    off = 0
+    for name, p in m.named_parameters():
+        if not p.requires_grad:
+            continue
+        if name.startswith('backbone.convs.') and name.endswith('.weight'):
+            conv[off:off + p.numel()] = True
+        off += (p.numel() + 63) // 64 * 64
+    assert off == one['flat'].numel() and int(conv.sum()) == 20 * 9 * 128 * 128
     scale = float(one['flat'].abs().max())
-    assert float((two[0]['flat'] - one['flat']).abs().max()) <= 1e-4 * scale
+    d = (two[0]['flat'] - one['flat']).abs()
+    print(f'world 2 vs world 1: conv weights {float(d[conv].max()) / scale:.2e}, other parameters {float(d[~conv].max()) / scale:.2e} of the largest gradient')
+    assert float(d[conv].max()) <= 1e-6 * scale          # measured 6e-8
+    assert float(d[~conv].max()) <= 1e-5 * scale         # measured 1.2e-7
     assert abs(two[0]['norm'] - one['norm']) <= 1e-4 * one['norm']
+    again = run_world(2, 'gpu', str(tmp_path / 'w2b'), extra)
+    assert torch.equal(again[0]['local_flat'][conv], two[0]['local_flat'][conv])      # bitwise reproducible
+    assert torch.equal(again[0]['flat'][conv], two[0]['flat'][conv])
 
 
 @pytest.mark.timeout(600)

@@ -388,3 +388,39 @@ def test_sample_finetune_gradient_bf16_chain_vs_emulation(dev, det_sd, monkeypat
     gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m.parameters() if p.grad is not None)).item()
     gr = torch.sqrt(sum((v.grad.double() ** 2).sum() for v in sdg.values() if v.grad is not None)).item()
     assert abs(gn - gr) <= 1e-2 * gr, (gn, gr)
+
+
+@pytest.mark.parametrize('tag', ['s16k6', 's128k50'])
+def test_bf16_chain_gate_audit_vs_fp32_oracle(dev, det_sd, tag):
+    """The gates test_sample_finetune_gradient_bf16_chain_vs_emulation hands to its emulation are the kernels' own; this
+    audit ties them to the fp32 oracle so that check is not self-referential.  For every Gumbel-softmax step of the chain,
+    on the SAME soft state the kernels saw, the fp32 oracle's pre-activations (O.cnn_forward(..., preacts=)) decide each
+    ReLU gate independently; a gate the kernels took differently must sit next to the kink — |fp32 pre-activation| below
+    GATE_BOUND x that layer's rms pre-activation (bf16 operands move a pre-activation by about 1e-2 of the layer's scale,
+    growing with depth) — and at most GATE_FLIPS of a layer's gates may differ.  A wrong gate away from the kink (an
+    indexing or layout slip in the mask) fails the first bar; systematically wrong gates fail the second."""
+    GATE_BOUND, GATE_FLIPS = 0.05, 0.01      # measured: 0.024 x rms, 0.24 % of a layer
+    g = load_golden(f'f5_finetune_{tag}.npz')
+    m, out, lx, cf, gates, (steps, trunc, temp, cft) = _run_f5(dev, det_sd, g, True)
+    assert len(gates) == trunc
+    n_hard = steps - trunc
+    worst_ratio, worst_frac = 0.0, 0.0
+    picks = range(trunc) if trunc <= 8 else (0, 1, trunc // 2, trunc - 2, trunc - 1)
+    for k in picks:
+        masks, y, f0 = gates[k]
+        x_k = lx[n_hard + k].detach().cpu()
+        pre = []
+        with torch.no_grad():
+            O.cnn_forward(det_sd, x_k, torch.zeros(x_k.shape[0]), preacts=pre)
+        kernel_gates = [mk.cpu().bool() for mk in masks] + [(y > 0).cpu()]
+        assert len(pre) == len(kernel_gates) == 21
+        for i, (c, kg) in enumerate(zip(pre, kernel_gates)):
+            c = c.permute(0, 2, 1)                                   # [B, L, C] like the kernels' masks
+            flipped = kg != (c > 0)
+            frac = float(flipped.float().mean())
+            rms = float(c.pow(2).mean().sqrt())
+            ratio = float(c[flipped].abs().max()) / rms if flipped.any() else 0.0
+            worst_ratio, worst_frac = max(worst_ratio, ratio), max(worst_frac, frac)
+            assert ratio <= GATE_BOUND, (tag, k, i, ratio, frac)
+            assert frac <= GATE_FLIPS, (tag, k, i, ratio, frac)
+    print(f'{tag}: worst |fp32 pre-activation| of a flipped gate = {worst_ratio:.4f} x layer rms; worst flipped fraction {worst_frac:.4f}')
