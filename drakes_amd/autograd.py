@@ -372,17 +372,19 @@ class _BackboneBf16Fn(torch.autograd.Function):
             assert sink is None, 'a gradient chain shares one sigma per forward'
             return _BackboneBf16Fn._forward_rows(ctx, st)
         M = B * L
-        feats = torch.empty(n + 1, B, L, C, dtype=torch.float32, device=dev)
+        ctx.per_layer = bool(ops.DENOISER_PER_LAYER)        # the backward runs in the mode that filled the saved blocks
+        feats, masks = ops.denoiser_saved_buffers(B, L, n, dev, ctx.per_layer)
         hs = torch.empty(n + 1, B, L, C, dtype=torch.bfloat16, device=dev)
-        masks = torch.empty(n, B, L, C, dtype=torch.uint8, device=dev)
         stats = torch.empty(2, n, M, dtype=torch.float32, device=dev)
         y = torch.empty(B, L, C, dtype=torch.float32, device=dev)
         logits = torch.empty(B, L, V, dtype=torch.float32, device=dev)
-        ops.denoiser_fwd_bf16(seq, pk, st, tbias[0], feats, hs, masks, stats[0], stats[1], y, logits)
+        ops.denoiser_fwd_bf16(seq, pk, st, tbias[0], feats, hs, masks, stats[0], stats[1], y, logits, per_layer=ctx.per_layer)
         ctx.st = st
         ctx.feats, ctx.hs, ctx.means, ctx.rstds, ctx.masks, ctx.y = feats, hs, stats[0], stats[1], masks, y
         if _BackboneBf16Fn.gate_log is not None:   # tests: the ReLU gates this forward took (see oracle/bf16_emulation.py)
-            _BackboneBf16Fn.gate_log.append((masks, y, feats[0]))
+            fused = ops.denoiser_is_fused(L, n, ctx.per_layer)
+            _BackboneBf16Fn.gate_log.append((fastpath.saved_masks_rows(masks, B, L, n, fused), y,
+                                             fastpath.saved_feats_rows(feats, B, L, n, fused)[0]))
         return logits
 
     @staticmethod
@@ -437,11 +439,11 @@ class _BackboneBf16Fn(torch.autograd.Function):
         dseq = torch.empty_like(seq) if (seq.dtype != torch.int64 and ctx.needs_input_grad[1]) else None
         kw = {}
         if want_w:
-            P = ops.workspace((M + 127) // 128 * sink.W * 4, dev)      # [workgroup][W]: every slot written by one launch
+            P = ops.workspace(ops.denoiser_bwd_slabs(B, L) * sink.W * 4, dev)   # [slab][W]: every slot written by one launch
             dw_t, db = sink.stem(dev)
             kw = dict(partials=P, acc=sink.group(ctx.sigma_key, ctx.sigma, ctx.temb), stem_dw=dw_t, stem_db=db)
         ops.denoiser_bwd_bf16(dlogits, seq, pk, st, fastpath._packed_T(bb), ctx.tbias[0], ctx.feats, ctx.masks, ctx.means,
-                              ctx.rstds, ctx.y, dcs, gr, dx=dseq, **kw)
+                              ctx.rstds, ctx.y, dcs, gr, dx=dseq, per_layer=ctx.per_layer, **kw)
         if want_w:
             sink.records.append((B, L, ctx.hs, dcs))
         ctx.feats = ctx.hs = ctx.masks = ctx.means = ctx.rstds = ctx.y = None

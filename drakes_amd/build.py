@@ -25,6 +25,7 @@ SOURCES = {
     'drk_train_bf16.hip': ['-ffp-contract=off'],
     'drk_conv_x3.hip': ['-ffp-contract=off'],
     'drk_train_chain.hip': ['-ffp-contract=off'],
+    'drk_train_fused_bf16.hip': ['-ffp-contract=off'],
 }
 COMMON = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function']
 

@@ -21,11 +21,26 @@
 #define CH_TAP_BYTES 32768L      // one tap of the fragment stream (drakes_amd/fastpath.py::_frag_tap)
 #define CH_SLOT (4 * DRK_C)      // floats one drk_layer_bwd_bf16 launch leaves per workgroup
 
+extern "C" int drk_denoiser_is_fused(int L, int n_layers, int flags) {
+  return L >= 1 && L <= 224 && n_layers >= 1 && n_layers <= 20 && !(flags & DRK_DENOISER_PER_LAYER);
+}
+
+extern "C" long drk_denoiser_feats_floats(int B, int L, int n_layers, int flags) {
+  if (B <= 0 || L <= 0 || n_layers < 1) return 0;
+  const long M = (long)B * L;
+  return drk_denoiser_is_fused(L, n_layers, flags) ? M * DRK_C + drk_train_fused_featn_floats(B, n_layers) : (n_layers + 1L) * M * DRK_C;
+}
+
+extern "C" long drk_denoiser_masks_bytes(int B, int L, int n_layers, int flags) {
+  if (B <= 0 || L <= 0 || n_layers < 1) return 0;
+  return drk_denoiser_is_fused(L, n_layers, flags) ? drk_train_fused_maskp_bytes(B, n_layers) : (long)n_layers * B * L * DRK_C;
+}
+
 extern "C" int drk_denoiser_fwd_bf16(const int64_t* x, const float* x_soft, const float* stem_w_t, const float* stem_b,
                                      const void* wstream, const float* vecs, const float* tbias, const float* head2_w,
                                      const float* head2_b, float* feats, void* hs, unsigned char* masks, float* means,
                                      float* rstds, float* y, float* logits, int B, int L, int n_layers, const int* dilations,
-                                     void* stream) {
+                                     int flags, void* stream) {
   DRK_SHAPE_GUARD("drk_denoiser_fwd_bf16");
   CARGCHECK((x || x_soft) && stem_w_t && stem_b && wstream && vecs && tbias && head2_w && head2_b && feats && hs && masks &&
                 means && rstds && y && logits && n_layers >= 1 && dilations,
@@ -33,7 +48,15 @@ extern "C" int drk_denoiser_fwd_bf16(const int64_t* x, const float* x_soft, cons
   const long M = (long)B * L, n = n_layers;
   const char* ws = (const char*)wstream;
   char* h = (char*)hs;
+  CARGCHECK(!(flags & ~DRK_DENOISER_PER_LAYER), "drk_denoiser_fwd_bf16 (unknown flag)");
   TRY(drk_stem_fwd(x, x_soft, stem_w_t, stem_b, feats, B, L, stream));
+  if (drk_denoiser_is_fused(L, n_layers, flags)) {
+    // one sequence per workgroup, all residual layers and final_conv.0 in ONE launch (drk_train_fused_bf16.hip); feats =
+    // feat0 then the lane-order snapshots, masks = the packed gates
+    TRY(drk_train_fwd_fused_bf16(wstream, vecs, tbias, feats, feats + M * DRK_C, hs, masks, means, rstds, y, B, L, n_layers,
+                                 dilations, stream));
+    return drk_head_out_fwd(y, head2_w, head2_b, logits, B, L, stream);
+  }
   TRY(drk_ln_fwd_bf16(feats, tbias, 0, vecs + DRK_C, vecs + 2 * DRK_C, h, means, rstds, B, L, stream));
   for (long i = 0; i < n; ++i) {
     const bool last = i + 1 == n;
@@ -48,6 +71,12 @@ extern "C" int drk_denoiser_fwd_bf16(const int64_t* x, const float* x_soft, cons
   return drk_head_out_fwd(y, head2_w, head2_b, logits, B, L, stream);
 }
 
+extern "C" long drk_denoiser_bwd_bf16_slabs(int B, int L) {
+  if (B <= 0 || L <= 0) return 0;
+  const long a = 2L * B, b = ((long)B * L + 127) / 128;
+  return a > b ? a : b;
+}
+
 extern "C" long drk_denoiser_bwd_bf16_slab_floats(int n_layers) {
   return n_layers < 1 ? 0 : (long)(n_layers + 1) * CH_SLOT + drk_head_bwd_bf16_slab_floats();
 }
@@ -57,8 +86,9 @@ extern "C" int drk_denoiser_bwd_bf16(const float* dlogits, const float* y, const
                                      const float* means, const float* rstds, void* dcs, int dcs_slots, float* gr,
                                      float* partials, float* acc, const int64_t* x, const float* x_soft,
                                      const float* stem_w_t, float* stem_dw, float* stem_db, float* dx, int B, int L,
-                                     int n_layers, const int* dilations, void* stream) {
+                                     int n_layers, const int* dilations, int flags, void* stream) {
   DRK_SHAPE_GUARD("drk_denoiser_bwd_bf16");
+  CARGCHECK(!(flags & ~DRK_DENOISER_PER_LAYER), "drk_denoiser_bwd_bf16 (unknown flag)");
   CARGCHECK(dlogits && y && head2_w && wstream_t && vecs && tbias && feats && masks && means && rstds && dcs && gr &&
                 n_layers >= 1 && dilations && (x || x_soft) && stem_w_t,
             "drk_denoiser_bwd_bf16");
@@ -72,6 +102,20 @@ extern "C" int drk_denoiser_bwd_bf16(const float* dlogits, const float* y, const
   auto dc = [&](long i) { return d + (dcs_slots == 2 ? (i & 1) : i) * M * 256; };
   auto slot = [&](long i) { return partials ? partials + i * CH_SLOT : nullptr; };
   TRY(drk_head_bwd_bf16(dlogits, y, head2_w, dc(n), slot(n + 1), W, B, L, stream));
+  if (drk_denoiser_is_fused(L, n_layers, flags)) {
+    // one sequence per workgroup, final_conv.0's input gradient and all residual layers in ONE launch; its column-sum
+    // partials come as two slabs per sequence, drk_head_bwd_bf16's as one per 128 rows: two ordered reductions
+    TRY(drk_train_bwd_fused_bf16(wstream_t, vecs, tbias, feats, feats + M * DRK_C, masks, means, rstds, dcs, dcs_slots, gr,
+                                 partials, W, B, L, n_layers, dilations, stream));
+    if (partials) {
+      const long head_off = (n + 1) * CH_SLOT;
+      TRY(drk_slab_reduce(partials, 2 * B, W, acc, head_off, stream));
+      TRY(drk_slab_reduce(partials + head_off, (int)((M + 127) / 128), W, acc + head_off, W - head_off, stream));
+      TRY(drk_colsum128(gr, stem_db, 1, M, stream));
+    }
+    if (stem_dw || dx) TRY(drk_stem_bwd(gr, x, x_soft, stem_w_t, stem_dw, dx, B, L, stream));
+    return DRK_OK;
+  }
   TRY(drk_layer_bwd_bf16(dc(n), wt + 9 * n * CH_TAP_BYTES, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, gr,
                          masks + (n - 1) * M * DRK_C, dc(n - 1), slot(n), W, B, L, 1, 0, 0, stream));
   for (long i = n - 1; i >= 0; --i)

@@ -279,3 +279,48 @@ def forward_bf16_layers(bb, seq, tbias, tb_stride, work=None):
     _lib.call('drk_head_bf16', _bf16_ptr(h[n & 1], 'h'), fp(st['wstream'][9 * n:]), fp(vec[3 * n + 1]), fp(pk['head2_w']),
               fp(pk['head2_b']), fp(logits), B, L, ops._stream())
     return logits
+
+
+# ---- the fused train kernels' lane-order saved blocks, mapped back onto rows (tests, gate logging) ----------------------
+FEATN_SEQ = 8 * 14 * 256      # floats per sequence and layer in featn (drk_train_fused_bf16.hip)
+MASKP_SEQ = 8 * 64            # uint64 per sequence and layer in maskp
+
+
+def _native_maps(L, device):
+    """For every (position p < L, channel c): the float offset inside a sequence's featn piece, and (word, bit) of its gate
+    inside a sequence's maskp piece — the accumulator layout of the fused kernels (wave = ct + 4 grp; slot = 2 t + s; lane =
+    16 g + n; position 16 (grp + 2 t) + (n ^ ((n & 8) >> 1)); channel 32 ct + 16 s + 4 g + j)."""
+    p = torch.arange(L, device=device)[:, None]
+    c = torch.arange(128, device=device)[None, :]
+    T, pn = p >> 4, p & 15
+    grp, t = T & 1, T >> 1
+    n = pn ^ ((pn & 8) >> 1)
+    ct, r = c >> 5, c & 31
+    sgrp, g, j = r >> 4, (r & 15) >> 2, r & 3
+    lane = 16 * g + n
+    wv = ct + 4 * grp
+    feat_off = ((wv * 14 + 2 * t + sgrp) * 64 + lane) * 4 + j
+    word = wv * 64 + lane
+    bit = 8 * t + 4 * sgrp + j
+    return feat_off, word, bit
+
+
+def saved_feats_rows(feats, B, L, n_layers, fused):
+    """The forward's `feats` buffer (ops.denoiser_saved_buffers) as float32 [n_layers+1, B, L, 128]."""
+    M = B * L
+    if not fused:
+        return feats[:(n_layers + 1) * M * 128].view(n_layers + 1, B, L, 128)
+    off, _, _ = _native_maps(L, feats.device)
+    featn = feats[M * 128:M * 128 + n_layers * B * FEATN_SEQ].view(n_layers, B, FEATN_SEQ)
+    rows = featn[:, :, off.reshape(-1)].view(n_layers, B, L, 128)
+    return torch.cat([feats[:M * 128].view(1, B, L, 128), rows])
+
+
+def saved_masks_rows(masks, B, L, n_layers, fused):
+    """The forward's `masks` buffer as uint8 [n_layers, B, L, 128] (1 = the ReLU gate was open)."""
+    if not fused:
+        return masks[:n_layers * B * L * 128].view(n_layers, B, L, 128)
+    _, word, bit = _native_maps(L, masks.device)
+    mp = masks[:n_layers * B * MASKP_SEQ * 8].view(torch.int64).view(n_layers, B, MASKP_SEQ)
+    w = mp[:, :, word.reshape(-1)].view(n_layers, B, L, 128)
+    return ((w >> bit) & 1).to(torch.uint8)

@@ -432,29 +432,62 @@ def conv_wgrad_bf16_multi(h_ptrs, dc_ptrs, n_seg, dwt, B, L, dilation, ws=None):
               dilation, _f(ws, 'workspace'), ws.numel() * 4, _stream())
 
 
-def denoiser_fwd_bf16(seq, pk, st, tbias, feats, hs, masks, means, rstds, y, logits):
+DENOISER_PER_LAYER = False     # tests / A-B runs: True takes the per-layer launches instead of the fused forward
+
+
+def denoiser_flags(per_layer=None):
+    return 1 if (DENOISER_PER_LAYER if per_layer is None else per_layer) else 0
+
+
+def denoiser_saved_buffers(B, L, n_layers, device, per_layer=None):
+    """(feats float32 [.], masks uint8 [.]) sized for drk_denoiser_fwd_bf16 in the mode the flags select: per-layer launches
+    keep row-major blocks ([n+1][B*L][128] floats, [n][B*L][128] gate bytes); the fused kernels keep feat0 row-major followed
+    by the residual snapshots in their lane order, and the gates packed (see include/drakes_hip.h)."""
+    lib, fl = _lib.load(), denoiser_flags(per_layer)
+    return (torch.empty(lib.drk_denoiser_feats_floats(B, L, n_layers, fl), dtype=torch.float32, device=device),
+            torch.empty(lib.drk_denoiser_masks_bytes(B, L, n_layers, fl), dtype=torch.uint8, device=device))
+
+
+def denoiser_is_fused(L, n_layers, per_layer=None):
+    return bool(_lib.load().drk_denoiser_is_fused(L, n_layers, denoiser_flags(per_layer)))
+
+
+def denoiser_fwd_bf16(seq, pk, st, tbias, feats, hs, masks, means, rstds, y, logits, per_layer=None):
     """drk_denoiser_fwd_bf16: the whole differentiable forward in one native call.  pk = CNNModel.packed(), st =
-    fastpath._packed(bb); tbias [n_layers,128] (one row for the batch); the outputs are whole blocks (see the header)."""
+    fastpath._packed(bb); tbias [n_layers,128] (one row for the batch); feats / masks: denoiser_saved_buffers(...) of the
+    same mode; the other outputs are whole row-major blocks (see the header)."""
     B, L = seq.shape[0], seq.shape[1]
     tok = seq.dtype == torch.int64
+    lib, fl, n = _lib.load(), denoiser_flags(per_layer), st['n_layers']
+    if feats.numel() < lib.drk_denoiser_feats_floats(B, L, n, fl) or masks.numel() < lib.drk_denoiser_masks_bytes(B, L, n, fl):
+        raise ValueError('feats / masks: too small for this mode (ops.denoiser_saved_buffers)')
     _lib.call('drk_denoiser_fwd_bf16', _i(seq, 'x') if tok else None, None if tok else _f(seq, 'x_soft'), _f(pk['stem_w'], 'stem_w'),
               _f(pk['stem_b'], 'stem_b'), _b16(st['wstream'], 'wstream'), _f(st['vecs'], 'vecs'), _f(tbias, 'tbias'),
               _f(pk['head2_w'], 'head2_w'), _f(pk['head2_b'], 'head2_b'), _f(feats, 'feats'), _b16(hs, 'hs'),
               _dev_ptr(masks, torch.uint8, 'masks'), _f(means, 'means'), _f(rstds, 'rstds'), _f(y, 'y'), _f(logits, 'logits'),
-              B, L, st['n_layers'], st['dil'], _stream())
+              B, L, n, st['dil'], fl, _stream())
     return logits
 
 
 def denoiser_bwd_bf16(dlogits, seq, pk, st, wstream_t, tbias, feats, masks, means, rstds, y, dcs, gr, partials=None, acc=None,
-                      stem_dw=None, stem_db=None, dx=None):
-    """drk_denoiser_bwd_bf16: the whole backward except weight gradients and the time path, in one native call."""
+                      stem_dw=None, stem_db=None, dx=None, per_layer=None):
+    """drk_denoiser_bwd_bf16: the whole backward except weight gradients and the time path, in one native call; `per_layer`
+    as the forward that filled feats / masks ran."""
     B, L = seq.shape[0], seq.shape[1]
     tok = seq.dtype == torch.int64
+    lib, fl, n = _lib.load(), denoiser_flags(per_layer), st['n_layers']
+    if feats.numel() < lib.drk_denoiser_feats_floats(B, L, n, fl) or masks.numel() < lib.drk_denoiser_masks_bytes(B, L, n, fl):
+        raise ValueError('feats / masks: too small for this mode (ops.denoiser_saved_buffers)')
     _lib.call('drk_denoiser_bwd_bf16', _f(dlogits, 'dlogits'), _f(y, 'y'), _f(pk['head2_w'], 'head2_w'), _b16(wstream_t, 'wstream_t'),
               _f(st['vecs'], 'vecs'), _f(tbias, 'tbias'), _f(feats, 'feats'), _dev_ptr(masks, torch.uint8, 'masks'),
               _f(means, 'means'), _f(rstds, 'rstds'), _b16(dcs, 'dcs'), dcs.shape[0], _f(gr, 'gr'), _f(partials, 'partials'),
               _f(acc, 'acc'), _i(seq, 'x') if tok else None, None if tok else _f(seq, 'x_soft'), _f(pk['stem_w'], 'stem_w'),
-              _f(stem_dw, 'stem_dw'), _f(stem_db, 'stem_db'), _f(dx, 'dx'), B, L, st['n_layers'], st['dil'], _stream())
+              _f(stem_dw, 'stem_dw'), _f(stem_db, 'stem_db'), _f(dx, 'dx'), B, L, n, st['dil'], fl, _stream())
+
+
+def denoiser_bwd_slabs(B, L):
+    """Partial slabs drk_denoiser_bwd_bf16 wants in its workspace."""
+    return int(_lib.load().drk_denoiser_bwd_bf16_slabs(B, L))
 
 
 def slab_reduce(slabs, n_slabs, stride, out, n):

@@ -353,27 +353,59 @@ int drk_slab_reduce(const float* slabs, int n_slabs, long stride, float* out, lo
  * dilations: HOST array [n_layers].  Outputs, one block each: feats float32 [n_layers+1][B*L][128] (residual snapshots),
  * hs bf16 [n_layers+1][B*L][128] (LayerNorm outputs; the last = bf16 of the last residual state), masks uint8
  * [n_layers][B*L][128], means / rstds float32 [n_layers][B*L], y float32 [B*L][128] (final_conv.0's ReLU output),
- * logits float32 [B*L][5]. */
+ * logits float32 [B*L][5].  flags: 0, or DRK_DENOISER_PER_LAYER (below). */
 int drk_denoiser_fwd_bf16(const int64_t* x, const float* x_soft, const float* stem_w_t, const float* stem_b,
                           const void* wstream, const float* vecs, const float* tbias, const float* head2_w,
                           const float* head2_b, float* feats, void* hs, unsigned char* masks, float* means, float* rstds,
-                          float* y, float* logits, int B, int L, int n_layers, const int* dilations, void* stream);
+                          float* y, float* logits, int B, int L, int n_layers, const int* dilations, int flags, void* stream);
+/* What drk_denoiser_fwd_bf16 runs for L <= 224 and <= 20 layers unless flags has DRK_DENOISER_PER_LAYER
+ * (drk_denoiser_is_fused): LayerNorm 0, all residual layers and final_conv.0 in ONE launch — one sequence per workgroup,
+ * the residual stream in registers, the LayerNorm outputs in LDS (drk_sample_bf16's body), the saved tensors streamed
+ * out — instead of 22 launches.  In that mode two of the saved blocks change FORMAT (only the fused backward reads them;
+ * every wave access is then one contiguous piece): `feats` = feat0 float32 [B*L][128] (the stem's output, row-major)
+ * followed by featn, the residual snapshots after layers 0..n-1 in the kernels' lane order
+ * (drk_train_fused_featn_floats(B, n_layers) floats); `masks` = maskp, the ReLU gates as one uint64 per lane and layer
+ * (drk_train_fused_maskp_bytes(B, n_layers) bytes); layouts: drakes_amd/csrc/drk_train_fused_bf16.hip, and
+ * drakes_amd/fastpath.py::saved_feats_rows / saved_masks_rows map them back onto rows.
+ * drk_denoiser_feats_floats / drk_denoiser_masks_bytes give the sizes of the two blocks for either mode;
+ * drk_denoiser_bwd_bf16 must be called with the flags the forward ran with. */
+#define DRK_DENOISER_PER_LAYER 1
+int drk_denoiser_is_fused(int L, int n_layers, int flags);
+long drk_denoiser_feats_floats(int B, int L, int n_layers, int flags);
+long drk_denoiser_masks_bytes(int B, int L, int n_layers, int flags);
+long drk_train_fused_featn_floats(int B, int n_layers);
+long drk_train_fused_maskp_bytes(int B, int n_layers);
+int drk_train_fwd_fused_bf16(const void* wstream, const float* vecs, const float* tbias, const float* feat0, float* featn,
+                             void* hs, void* maskp, float* means, float* rstds, float* y, int B, int L, int n_layers,
+                             const int* dilations, void* stream);
 /* Its backward except the convolutions' weight gradients and the time path (torch autograd over models/dnaconv.py:74-110
  * in the reference): drk_head_bwd_bf16, (n_layers + 1) x drk_layer_bwd_bf16, drk_relu_bwd, drk_slab_reduce,
  * drk_colsum128, drk_stem_bwd in one call.  wstream_t: drakes_amd/fastpath.py::pack_stream_T; feats, masks, means, rstds,
  * y: the forward's blocks.  dcs bf16 [dcs_slots][B*L][128]: dcs_slots = n_layers + 1 keeps every convolution's gated
  * output gradient (slot i pairs with hs[i] in drk_conv_wgrad_bf16_multi; slot n_layers = final_conv.0), dcs_slots = 2
- * ping-pongs (a frozen model; partials must be NULL).  gr: float32 [B*L][128] work buffer.  partials: ceil(B*L / 128)
+ * ping-pongs (a frozen model; partials must be NULL).  gr: float32 [B*L][128] work buffer.  partials:
+ * drk_denoiser_bwd_bf16_slabs(B, L) = max(2 B, ceil(B*L / 128))
  * slabs of drk_denoiser_bwd_bf16_slab_floats(n_layers) floats — slot i < n_layers: layer i's [4][128] of
  * drk_layer_bwd_bf16, slot n_layers: final_conv.0's input-gradient launch, then drk_head_bwd_bf16's slab — summed in
  * order into acc (+=, same length); stem_dw [9][5][128], stem_db [128] (+=, atomics); dx float32 [B*L][5] (x_soft only,
  * may be NULL).  partials, acc, stem_dw, stem_db: all or none. */
 long drk_denoiser_bwd_bf16_slab_floats(int n_layers);
+long drk_denoiser_bwd_bf16_slabs(int B, int L);
 int drk_denoiser_bwd_bf16(const float* dlogits, const float* y, const float* head2_w, const void* wstream_t,
                           const float* vecs, const float* tbias, const float* feats, const unsigned char* masks,
                           const float* means, const float* rstds, void* dcs, int dcs_slots, float* gr, float* partials,
                           float* acc, const int64_t* x, const float* x_soft, const float* stem_w_t, float* stem_dw,
-                          float* stem_db, float* dx, int B, int L, int n_layers, const int* dilations, void* stream);
+                          float* stem_db, float* dx, int B, int L, int n_layers, const int* dilations, int flags, void* stream);
+/* What drk_denoiser_bwd_bf16 runs between drk_head_bwd_bf16 and the stem's backward for L <= 224 and <= 20 layers unless
+ * flags has DRK_DENOISER_PER_LAYER: final_conv.0's input gradient and every residual layer's backward (the arithmetic of
+ * drk_layer_bwd_bf16) in ONE launch, one sequence per workgroup, the residual-gradient stream in registers, the gated
+ * gradients in LDS.  feat0 / featn / maskp: the fused forward's blocks (above).  dcs slot n_layers (mod dcs_slots) is read (drk_head_bwd_bf16's output), slots n_layers-1 .. 0 are
+ * written when dcs_slots = n_layers + 1; dpre float32 [B*L][128] = dL/d(stem pre-activation) (the ReLU gate of the stem
+ * applied); partials: 2 B slabs (two per sequence) of part_stride >= 512 (n_layers + 1) floats, slot i at 512 i. */
+int drk_train_bwd_fused_bf16(const void* wstream_t, const float* vecs, const float* tbias, const float* feat0,
+                             const float* featn, const void* maskp, const float* means, const float* rstds, void* dcs,
+                             int dcs_slots, float* dpre, float* partials, long part_stride, int B, int L, int n_layers,
+                             const int* dilations, void* stream);
 
 #ifdef __cplusplus
 }

@@ -424,3 +424,119 @@ def test_bf16_chain_gate_audit_vs_fp32_oracle(dev, det_sd, tag):
             assert ratio <= GATE_BOUND, (tag, k, i, ratio, frac)
             assert frac <= GATE_FLIPS, (tag, k, i, ratio, frac)
     print(f'{tag}: worst |fp32 pre-activation| of a flipped gate = {worst_ratio:.4f} x layer rms; worst flipped fraction {worst_frac:.4f}')
+
+
+@pytest.mark.parametrize('B,L,soft', [(3, 200, True), (2, 200, False), (130, 200, True), (2, 77, True), (1, 224, False),
+                                      (2, 208, True), (3, 193, True), (2, 9, False)])
+def test_fused_train_forward_matches_per_layer_launches(dev, det_sd, B, L, soft):
+    """drk_train_fwd_fused_bf16 (LayerNorm 0 + 20 residual layers + final_conv.0 in one launch, one sequence per
+    workgroup; the specialised build for 192 < L <= 208, the generic one otherwise) against the per-layer launch sequence
+    it replaces: residual snapshots, LayerNorm outputs, statistics, y and logits to fp32 rounding, gates equal away from
+    the kink.  Both run the same MFMA order on the same bf16 operands."""
+    m = drakes_amd.Diffusion(drakes_amd.default_config(length=L)).to(dev)
+    m.load_state_dict(det_sd)
+    bb = m.backbone
+    pk, st = bb.packed(), fastpath._packed(bb)
+    n = bb.num_layers
+    gen = np.random.Generator(np.random.PCG64(B * 1000 + L))
+    x = torch.from_numpy(gen.dirichlet(np.ones(5) * 0.5, (B, L)).astype(np.float32)) if soft else torch.from_numpy(gen.integers(0, 5, (B, L)))
+    x = x.to(dev)
+    tbias = bb.time_bias(torch.full((1,), 0.7, device=dev))[0]
+    outs = []
+    for per_layer in (True, False):
+        feats, masks = ops.denoiser_saved_buffers(B, L, n, dev, per_layer)
+        feats.fill_(9.0), masks.fill_(7)
+        blocks = dict(feats=feats, masks=masks, hs=torch.full((n + 1, B, L, 128), 9.0, dtype=torch.bfloat16, device=dev),
+                      means=torch.full((n, B * L), 9.0, device=dev), rstds=torch.full((n, B * L), 9.0, device=dev),
+                      y=torch.full((B, L, 128), 9.0, device=dev), logits=torch.full((B, L, 5), 9.0, device=dev))
+        ops.denoiser_fwd_bf16(x, pk, st, tbias, per_layer=per_layer, **blocks)
+        torch.cuda.synchronize()
+        fused = ops.denoiser_is_fused(L, n, per_layer)
+        assert fused == (not per_layer)
+        blocks['feats'] = fastpath.saved_feats_rows(feats, B, L, n, fused)
+        blocks['masks'] = fastpath.saved_masks_rows(masks, B, L, n, fused)
+        outs.append({k: v.float().cpu() for k, v in blocks.items()})
+    ref, got = outs
+    # LayerNorm 0 sees identical inputs: statistics to fp32 rounding, its bf16 output equal up to roundings that tip on an
+    # fp32 last-bit difference; every such tip (2^-8 of one h element) moves the conv outputs it feeds by ~1e-4 of their
+    # scale, and 20 residual layers accumulate them: the whole-network bar is the bf16 path's own (1e-2 of the scale).
+    rel = lambda a_, b_: float((a_ - b_).abs().max()) / max(float(b_.abs().max()), 1e-30)
+    assert rel(got['means'][0], ref['means'][0]) <= 1e-5 and rel(got['rstds'][0], ref['rstds'][0]) <= 1e-5
+    assert float((got['hs'][0] != ref['hs'][0]).float().mean()) <= 2e-3 and rel(got['hs'][0], ref['hs'][0]) <= 2 ** -7
+    assert rel(got['feats'][1], ref['feats'][1]) <= 5e-4
+    per_layer = [rel(got['feats'][i], ref['feats'][i]) for i in range(1, n + 1)]
+    worst = {k: rel(got[k], ref[k]) for k in ('feats', 'hs', 'means', 'rstds', 'y', 'logits')}
+    print(f'B={B} L={L}: fused vs per-layer, max |d| / max |ref|:', {k: f'{v:.1e}' for k, v in worst.items()},
+          'feats by layer:', ' '.join(f'{v:.0e}' for v in per_layer))
+    for k in ('feats', 'means', 'rstds', 'y', 'logits'):
+        assert worst[k] <= 1e-2, (k, worst[k])
+    assert worst['hs'] <= 3e-2
+    d = ref['feats'][1:] - ref['feats'][:-1]                         # relu(c): > 0 exactly where the gate is open
+    # gates: equal wherever the pre-activation clears the kink
+    same = got['masks'] == ref['masks']
+    assert bool(same[d > 5e-2].all()) and float((~same).float().mean()) <= 5e-3
+    assert int(got['masks'].max()) <= 1
+
+
+@pytest.mark.parametrize('B,L,soft,want_w', [(3, 200, True, True), (2, 200, False, True), (130, 200, True, True), (2, 77, True, True),
+                                             (1, 224, False, True), (2, 208, True, False), (3, 193, True, True), (2, 9, True, True)])
+def test_fused_train_backward_matches_per_layer_launches(dev, det_sd, B, L, soft, want_w):
+    """drk_train_bwd_fused_bf16 (final_conv.0's input gradient + 20 residual layers' backward in one launch) inside
+    drk_denoiser_bwd_bf16 against the per-layer launches (drk_layer_bwd_bf16, each checked against float64 above) on the
+    same saved forward: the gated gradients dc of every layer, dL/d(stem pre-activation), the input gradient, the reduced
+    column sums and the stem gradients.  bf16 roundings of dc may tip on an fp32 last-bit difference (2^-8 of one
+    element), which the layers below carry on: 1e-2 of each tensor's scale over the whole stack, 1e-3 for the top layers."""
+    m = drakes_amd.Diffusion(drakes_amd.default_config(length=L)).to(dev)
+    m.load_state_dict(det_sd)
+    bb = m.backbone
+    pk, st = bb.packed(), fastpath._packed(bb)
+    wT = fastpath._packed_T(bb)
+    n = bb.num_layers
+    gen = np.random.Generator(np.random.PCG64(B * 1000 + L + 5))
+    x = torch.from_numpy(gen.dirichlet(np.ones(5) * 0.5, (B, L)).astype(np.float32)) if soft else torch.from_numpy(gen.integers(0, 5, (B, L)))
+    x = x.to(dev)
+    dlogits = torch.from_numpy(gen.standard_normal((B, L, 5)).astype(np.float32)).to(dev)
+    tbias = bb.time_bias(torch.full((1,), 0.7, device=dev))[0]
+    W = int(AG.GradSink(bb).W)
+    nslab = ops.denoiser_bwd_slabs(B, L)
+    outs = []
+    # ONE forward (fused); the per-layer backward reads the same saved values converted to its row-major formats (a second
+    # forward in the other mode would differ by rounding tips, and a gate that tips flips a whole dc element)
+    feats, masks = ops.denoiser_saved_buffers(B, L, n, dev, False)
+    fw = dict(feats=feats, masks=masks, hs=torch.empty(n + 1, B, L, 128, dtype=torch.bfloat16, device=dev),
+              means=torch.empty(n, B * L, device=dev), rstds=torch.empty(n, B * L, device=dev),
+              y=torch.empty(B, L, 128, device=dev), logits=torch.empty(B, L, 5, device=dev))
+    ops.denoiser_fwd_bf16(x, pk, st, tbias, per_layer=False, **fw)
+    rows = dict(fw, feats=fastpath.saved_feats_rows(feats, B, L, n, True).contiguous().view(-1),
+                masks=fastpath.saved_masks_rows(masks, B, L, n, True).contiguous().view(-1))
+    for per_layer in (True, False):
+        fw_m = rows if per_layer else fw
+        o = dict(dcs=torch.full((n + 1 if want_w else 2, B, L, 128), 9.0, dtype=torch.bfloat16, device=dev),
+                 gr=torch.full((B, L, 128), 9.0, device=dev), dx=torch.full((B, L, 5), 9.0, device=dev) if soft else None)
+        kw = {}
+        if want_w:
+            kw = dict(partials=torch.full((nslab * W,), 5.0, device=dev), acc=torch.zeros(W, device=dev),
+                      stem_dw=torch.zeros(9, 5, 128, device=dev), stem_db=torch.zeros(1, 128, device=dev))
+        ops.denoiser_bwd_bf16(dlogits, x, pk, st, wT, tbias, fw_m['feats'], fw_m['masks'], fw_m['means'], fw_m['rstds'], fw_m['y'],
+                              o['dcs'], o['gr'], dx=o['dx'], per_layer=per_layer, **kw)
+        torch.cuda.synchronize()
+        o.update({k: v for k, v in kw.items() if k != 'partials'})
+        outs.append({k: v.float().cpu() for k, v in o.items() if v is not None})
+    ref, got = outs
+    rel = lambda a_, b_: float((a_ - b_).abs().max()) / max(float(b_.abs().max()), 1e-30)
+    worst = {k: rel(got[k], ref[k]) for k in ref if k != 'dcs'}
+    if want_w:
+        by_layer = [rel(got['dcs'][i], ref['dcs'][i]) for i in reversed(range(n + 1))]
+        print(f'B={B} L={L}: fused vs per-layer backward:', {k: f'{v:.1e}' for k, v in worst.items()}, 'dc from the top:',
+              ' '.join(f'{v:.0e}' for v in by_layer))
+        assert by_layer[0] == 0.0 and by_layer[1] <= 2 ** -7 and max(by_layer) <= 3e-2   # head_bwd's own; one conv; the stack
+        lay = lambda t: t[:(n + 1) * 512].view(n + 1, 4, 128)
+        for q, name in enumerate(('dgamma', 'dbeta', 'dtbias', 'dbias below')):
+            e = rel(lay(got['acc'])[:n, q] if q < 3 else lay(got['acc'])[:, q], lay(ref['acc'])[:n, q] if q < 3 else lay(ref['acc'])[:, q])
+            assert e <= 1e-2, (name, e)
+        assert rel(got['acc'][(n + 1) * 512:], ref['acc'][(n + 1) * 512:]) <= 1e-6       # drk_head_bwd_bf16's slab: same launch
+    else:
+        print(f'B={B} L={L}: fused vs per-layer backward (frozen):', {k: f'{v:.1e}' for k, v in worst.items()})
+    for k, v in worst.items():
+        if k != 'acc':
+            assert v <= 1e-2, (k, v)
