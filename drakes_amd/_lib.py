@@ -62,6 +62,7 @@ SIGNATURES = {
     'drk_head_bwd_bf16': [_P, _P, _P, _P, _P, c_long, c_int, c_int, _P],
     'drk_conv_wgrad_bf16_multi': [_P, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, c_long, _P],
     'drk_slab_reduce': [_P, c_int, c_long, _P, c_long, _P],
+    'drk_slab_reduce2': [_P, c_int, c_long, _P, c_long, _P, _P],
     'drk_denoiser_fwd_bf16': [_P] * 16 + [c_int, c_int, c_int, _P, c_int, _P],
     'drk_train_fwd_fused_bf16': [_P] * 10 + [c_int, c_int, c_int, _P, _P],
     'drk_denoiser_bwd_bf16': [_P] * 11 + [c_int] + [_P] * 9 + [c_int, c_int, c_int, _P, c_int, _P],
@@ -79,6 +80,7 @@ HOST_QUERIES = {
     'drk_denoiser_bwd_bf16_slab_floats': [c_int],
     'drk_denoiser_bwd_bf16_slabs': [c_int, c_int],
     'drk_denoiser_is_fused': [c_int, c_int, c_int],
+    'drk_slab_reduce2_tmp_floats': [c_int, c_long],
     'drk_denoiser_feats_floats': [c_int, c_int, c_int, c_int],
     'drk_denoiser_masks_bytes': [c_int, c_int, c_int, c_int],
     'drk_train_fused_featn_floats': [c_int, c_int],

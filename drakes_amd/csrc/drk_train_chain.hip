@@ -71,10 +71,13 @@ extern "C" int drk_denoiser_fwd_bf16(const int64_t* x, const float* x_soft, cons
   return drk_head_out_fwd(y, head2_w, head2_b, logits, B, L, stream);
 }
 
+// Slabs of the partials workspace: the launches' own (two per sequence on the fused path, one per 128 rows otherwise)
+// plus room for the first stage of the ordered two-stage reduction (one slab per 16).
 extern "C" long drk_denoiser_bwd_bf16_slabs(int B, int L) {
   if (B <= 0 || L <= 0) return 0;
   const long a = 2L * B, b = ((long)B * L + 127) / 128;
-  return a > b ? a : b;
+  const long m = a > b ? a : b;
+  return m + (m + 15) / 16 + 1;
 }
 
 extern "C" long drk_denoiser_bwd_bf16_slab_floats(int n_layers) {
@@ -109,7 +112,9 @@ extern "C" int drk_denoiser_bwd_bf16(const float* dlogits, const float* y, const
                                  partials, W, B, L, n_layers, dilations, stream));
     if (partials) {
       const long head_off = (n + 1) * CH_SLOT;
-      TRY(drk_slab_reduce(partials, 2 * B, W, acc, head_off, stream));
+      const long nown = 2L * B > (M + 127) / 128 ? 2L * B : (M + 127) / 128;
+      float* tmp = partials + nown * W;             // the workspace's tail (drk_denoiser_bwd_bf16_slabs)
+      TRY(drk_slab_reduce2(partials, 2 * B, W, acc, head_off, tmp, stream));
       TRY(drk_slab_reduce(partials + head_off, (int)((M + 127) / 128), W, acc + head_off, W - head_off, stream));
       TRY(drk_colsum128(gr, stem_db, 1, M, stream));
     }

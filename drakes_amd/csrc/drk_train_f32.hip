@@ -860,6 +860,52 @@ int drk_slab_reduce_launch(const float* slabs, int n_slabs, long stride, float* 
   return DRK_OK;
 }
 
+// Stage 1 of the two-stage form: group g = blockIdx.y sums slabs [g * per, min((g + 1) * per, n_slabs)) in order and STORES
+// the sum as slab g of `tmp` (stride n): many slabs of a short vector then run on groups x columns workgroups instead of
+// a dozen, each with a chain of n_slabs dependent-latency loads.  Stage 2 is k_slab_reduce over the groups.
+__global__ void __launch_bounds__(256) k_slab_reduce_groups(const float* __restrict__ slabs, int n_slabs, long stride, int per,
+                                                            float* __restrict__ tmp, long n4) {
+  const int g = blockIdx.y;
+  const int s0 = g * per, s1 = (s0 + per < n_slabs) ? s0 + per : n_slabs;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int k0 = s0; k0 < s1; k0 += 8) {
+      f32x4 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (k0 + j < s1) v[j] = ((const f32x4*)(slabs + (long)(k0 + j) * stride))[i];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += v[j];
+    }
+    ((f32x4*)(tmp + (long)g * n4 * 4))[i] = s;
+  }
+}
+
+// out[i] += sum over slabs, in a FIXED order (groups of `DRK_REDUCE_GROUP_SLABS` consecutive slabs, then the groups):
+// tmp holds drk_slab_reduce2_tmp_floats(n_slabs, n) floats.
+#define DRK_REDUCE_GROUP_SLABS 16
+extern "C" long drk_slab_reduce2_tmp_floats(int n_slabs, long n) {
+  if (n_slabs <= 0 || n <= 0) return 0;
+  return (long)((n_slabs + DRK_REDUCE_GROUP_SLABS - 1) / DRK_REDUCE_GROUP_SLABS) * n;
+}
+
+extern "C" int drk_slab_reduce2(const float* slabs, int n_slabs, long stride, float* out, long n, float* tmp, void* stream) {
+  if (n_slabs < 0 || n < 0 || (n & 3) || (n && (!slabs || !out || !tmp)) || (((uintptr_t)slabs | (uintptr_t)out | (uintptr_t)tmp) & 15) ||
+      (stride & 3))
+    return drk_set_error_msg(DRK_EINVAL, "drk_slab_reduce2: n % 4 == 0, stride % 4 == 0, 16-byte aligned pointers, tmp given");
+  if (n == 0 || n_slabs == 0) return DRK_OK;
+  const int groups = (n_slabs + DRK_REDUCE_GROUP_SLABS - 1) / DRK_REDUCE_GROUP_SLABS;
+  const long n4 = n / 4;
+  long gx = (n4 + 255) / 256;
+  if (gx > 1024) gx = 1024;
+  hipLaunchKernelGGL(k_slab_reduce_groups, dim3((unsigned)gx, (unsigned)groups), dim3(256), 0, (hipStream_t)stream, slabs, n_slabs,
+                     stride, DRK_REDUCE_GROUP_SLABS, tmp, n4);
+  DRK_CHECK_LAUNCH();
+  return drk_slab_reduce_launch(tmp, groups, n, out, n, (hipStream_t)stream);
+}
+
 extern "C" int drk_slab_reduce(const float* slabs, int n_slabs, long stride, float* out, long n, void* stream) {
   if (n_slabs < 0 || n < 0 || (n & 3) || (n && (!slabs || !out)) || (((uintptr_t)slabs | (uintptr_t)out) & 15) || (stride & 3))
     return drk_set_error_msg(DRK_EINVAL, "drk_slab_reduce: n % 4 == 0, stride % 4 == 0, 16-byte aligned pointers");

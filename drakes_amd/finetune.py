@@ -69,6 +69,7 @@ def sample_finetune_gradient(model, num_steps=None, eps=1e-5, eval_sp_size=None,
     # fine-tune loop's KL term evaluates the same model on the same tensor (finetune_loop.kl_of_step)
     model._soft_logits_cache = {}
     shared = None
+    sig = None
     flat = None                                 # the parameters as one vector: one gradient per soft step, not 129
     sink = None                                 # bf16 soft steps: parameter gradients deferred to the end of the chain
     n_hard = max(num_steps - trunc, 0)
@@ -80,13 +81,21 @@ def sample_finetune_gradient(model, num_steps=None, eps=1e-5, eval_sp_size=None,
         from . import fastpath
         with torch.no_grad():
             x, traj = fastpath.hard_steps_bf16(model, batch, table, n_hard, seed, sample_offset, uniforms)
+            # the four record lists of the hard steps (:616-626), built for all steps at once and handed out as views:
+            # a handful of launches instead of six per step
+            tr = traj.to(torch.int64)                                                     # [n_hard, B, L]
+            lx_all = F.one_hot(tr, num_classes=model.vocab_size).to(torch.float32)        # [n_hard, B, L, 5]
+            cf_all = (tr != model.mask_index).to(torch.int64).unsqueeze(-1)               # [n_hard, B, L, 1]
+            sched = torch.tensor([[row[1], row[2]] for row in table[:n_hard]], dtype=torch.float32,
+                                 pin_memory=True).to(dev, non_blocking=True)   # (pinned: the copy does not wait for queued kernels)
+            ct_all = sched[:, 0, None].expand(n_hard, batch).contiguous()
+            mc_all = sched[:, 1, None, None, None].expand(n_hard, batch, 1, 1).contiguous()
             for i in range(n_hard):
-                xi = traj[i].to(torch.int64)
-                last_x_list.append(F.one_hot(xi, num_classes=model.vocab_size).to(torch.float32))
-                condt_list.append(torch.full((batch,), table[i][1], dtype=torch.float32, device=dev))
+                last_x_list.append(lx_all[i])
+                condt_list.append(ct_all[i])
                 condt_list[-1]._drk_uniform = float(table[i][1])
-                move_chance_t_list.append(torch.full((batch, 1, 1), table[i][2], dtype=torch.float32, device=dev))
-                copy_flag_list.append((xi != model.mask_index).to(torch.int64).unsqueeze(-1))
+                move_chance_t_list.append(mc_all[i])
+                copy_flag_list.append(cf_all[i])
         first = n_hard
     for i in range(first, num_steps):
         _, sigma_t, mc_t, mc_s = table[i]
@@ -106,7 +115,8 @@ def sample_finetune_gradient(model, num_steps=None, eps=1e-5, eval_sp_size=None,
         else:                                                               # soft step (:621, :552-586)
             if x.ndim == 2:
                 x = F.one_hot(x, num_classes=model.vocab_size).to(torch.float32)
-            sig = torch.full((1,), sigma_t if model.time_conditioning else 0.0, dtype=torch.float32, device=dev)
+            if model.time_conditioning or sig is None:        # (one sigma tensor for all soft steps when it is constant)
+                sig = torch.full((1,), sigma_t if model.time_conditioning else 0.0, dtype=torch.float32, device=dev)
             if flat is None and torch.is_grad_enabled() and getattr(model, 'hip_flat_grads', True):
                 if soft_bf16:
                     sink, flat = autograd.grad_chain(bb)

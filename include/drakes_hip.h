@@ -344,6 +344,11 @@ int drk_conv_wgrad_bf16_multi(const void* const* h_ptrs, const void* const* dc_p
 /* out[i] += slabs[0][i] + slabs[1][i] + ... + slabs[n_slabs-1][i], in that order, i < n (n % 4 == 0, 16-byte aligned
  * pointers, slab s at slabs + s * stride): the ordered second pass of the split reductions above. */
 int drk_slab_reduce(const float* slabs, int n_slabs, long stride, float* out, long n, void* stream);
+/* The same sum in two launches for MANY slabs of a short vector (the fused backward's 2 B partial slabs): groups of 16
+ * consecutive slabs are summed in order into tmp (drk_slab_reduce2_tmp_floats(n_slabs, n) floats, 16-byte aligned), then
+ * the groups in order into out: a fixed order, so the result is reproducible bit for bit. */
+long drk_slab_reduce2_tmp_floats(int n_slabs, long n);
+int drk_slab_reduce2(const float* slabs, int n_slabs, long stride, float* out, long n, float* tmp, void* stream);
 
 /* The whole differentiable denoiser forward (models/dnaconv.py:74-110 on the bf16 layer kernels) as ONE call: the launch
  * sequence drk_stem_fwd, drk_ln_fwd_bf16, n_layers x drk_layer_bf16 (ReLU gates and LayerNorm statistics kept),
@@ -384,7 +389,7 @@ int drk_train_fwd_fused_bf16(const void* wstream, const float* vecs, const float
  * y: the forward's blocks.  dcs bf16 [dcs_slots][B*L][128]: dcs_slots = n_layers + 1 keeps every convolution's gated
  * output gradient (slot i pairs with hs[i] in drk_conv_wgrad_bf16_multi; slot n_layers = final_conv.0), dcs_slots = 2
  * ping-pongs (a frozen model; partials must be NULL).  gr: float32 [B*L][128] work buffer.  partials:
- * drk_denoiser_bwd_bf16_slabs(B, L) = max(2 B, ceil(B*L / 128))
+ * drk_denoiser_bwd_bf16_slabs(B, L) (the launches' own max(2 B, ceil(B*L / 128)) and the reduction's first stage)
  * slabs of drk_denoiser_bwd_bf16_slab_floats(n_layers) floats — slot i < n_layers: layer i's [4][128] of
  * drk_layer_bwd_bf16, slot n_layers: final_conv.0's input-gradient launch, then drk_head_bwd_bf16's slab — summed in
  * order into acc (+=, same length); stem_dw [9][5][128], stem_db [128] (+=, atomics); dx float32 [B*L][5] (x_soft only,
