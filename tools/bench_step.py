@@ -58,12 +58,15 @@ def main():
     s = ops._stream()
     P = lambda t: t.data_ptr()
     mc_t, mc_s = 0.49950498, 0.49170041
+    mc_rows = torch.tensor([[mc_t, mc_s]], device=dev).repeat(B, 1).contiguous()      # per-row timesteps (round 2)
 
     cases = [
         ('reverse_step_hard, Philox in-kernel, all masked', 36,
          lambda: _lib.call('drk_reverse_step_hard', P(logits), P(x_mask), None, P(out_tok), B, L, mc_t, mc_s, None, 7, 3, 0, s)),
         ('reverse_step_hard, Philox in-kernel, half masked', 36,
          lambda: _lib.call('drk_reverse_step_hard', P(logits), P(x_half), None, P(out_tok), B, L, mc_t, mc_s, None, 7, 3, 0, s)),
+        ('reverse_step_hard, Philox in-kernel, all masked, per-row mc', 36,
+         lambda: _lib.call('drk_reverse_step_hard', P(logits), P(x_mask), None, P(out_tok), B, L, mc_t, mc_s, P(mc_rows), 7, 3, 0, s)),
         ('reverse_step_hard, injected uniforms, all masked', 56,
          lambda: _lib.call('drk_reverse_step_hard', P(logits), P(x_mask), P(u), P(out_tok), B, L, mc_t, mc_s, None, 7, 3, 0, s)),
         ('subs_fwd (tokens)', 48,
@@ -95,7 +98,7 @@ def main():
     rows.append({'kernel': 'reverse_step_hard at B=1024 (launch-bound)', 'positions': Bs * L, 'median_ms': med})
     if a.json:
         with open(a.json, 'w') as f:
-            json.dump(rows, f, indent=1)
+            json.dump({'drk_version': _lib.load().drk_version(), 'rows': rows}, f, indent=1)
 
 
 if __name__ == '__main__':
