@@ -257,10 +257,10 @@ _WORKSPACE = {}
 
 
 def workspace(nbytes, device):
-    """A per-device scratch tensor of at least `nbytes` (split-K partial slabs).  Grown on demand, reused by every
-    call on that device: calls are ordered by the stream they share (torch's current stream); callers running several
-    streams pass their own workspace tensors instead."""
-    key = (device.type, device.index)
+    """A scratch tensor of at least `nbytes` (split-K partial slabs) per (device, current stream).  Grown on demand and
+    reused by every call on that stream, which orders them; work on another stream (a second model's backward, side-stream
+    weight gradients) gets its own buffer instead of racing on this one."""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
     t = _WORKSPACE.get(key)
     if t is None or t.numel() * 4 < nbytes:
         t = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
