@@ -48,14 +48,15 @@ PEAK = {'bf16': 2500.0, 'fp32': 157.3}            # TFLOP/s dense MFMA, MI355X_M
 # for 16-B-per-lane loads on gfx950): tools/pmc_traffic.sh.  A recorded measurement (a process cannot collect PMC
 # counters on itself): it names the library version it was taken on and is printed ONLY when drk_version() still is
 # that version — a changed kernel reports traffic null until the passes are re-run.
-PMC_TRAFFIC = {('bf16', 1024): {'drk_version': 202,
-                                'bytes_per_launch': 27219523648.0, 'fetch_bytes': 26716522496.0, 'write_bytes': 503001152.0,
+PMC_TRAFFIC = {('bf16', 1024): {'drk_version': 300,
+                                'bytes_per_launch': 27219472960.0, 'fetch_bytes': 26716467840.0, 'write_bytes': 503005120.0,
                                 'algorithmic_bytes': 7.6e6,
                                 'note': 'L2-to-fabric requests; Infinity-Cache hits are counted: the 5.9 MB bf16 weight '
                                         'stream outgrows a 4 MB per-XCD L2 and is re-fetched from the 256 MB Infinity '
                                         'Cache; 0.25 TB/s = 3.1 % of HBM peak, the launch is MFMA-bound; the writes are '
-                                        'scratch spills of the per-forward stem/head block (152 B/lane), tokens out are 1.6 MB',
-                                'source': 'profiles/r2_bf16_v202_pmc_traffic.json'}}
+                                        'scratch spills of the per-forward stem/head block (140 B/lane reserved; 2 dwords per lane and forward '
+                                        'actually written), tokens out are 1.6 MB',
+                                'source': 'profiles/r3_bf16_v300_pmc_traffic.json'}}
 
 
 def _median(v):
