@@ -135,3 +135,75 @@ def test_narrow_model_parameter_images():
             assert torch.equal(bb.narrow(name, w), p.detach()), name
     with pytest.raises(NotImplementedError):
         drakes_amd.Diffusion(drakes_amd.default_config(hidden_dim=20))
+
+
+def test_native_denoiser_entry_points_reject_bad_arguments():
+    """Argument errors of the round-3 entry points come back as DRK_EINVAL before anything is launched (so this runs
+    without a GPU): the pointers below are never dereferenced."""
+    lib = _lib.load()
+    P = 0x10000                                   # any non-null, 16-byte aligned value
+    dil = (ctypes.c_int * 20)(*([1] * 20))
+    dp = ctypes.cast(dil, ctypes.c_void_p)
+
+    def fwd(x=P, feats=P, B=2, L=200, n=20, dilations=dp, flags=0):
+        return ('drk_denoiser_fwd_bf16', x, None if x is None else None, P, P, P, P, P, P, P, feats, P, P, P, P, P, P, B, L, n,
+                dilations, flags, None)
+
+    def bwd(slots=21, partials=P, acc=P, stem_dw=P, stem_db=P, B=2, L=200, n=20, flags=0, dlogits=P):
+        return ('drk_denoiser_bwd_bf16', dlogits, P, P, P, P, P, P, P, P, P, P, slots, P, partials, acc, P, None, P, stem_dw,
+                stem_db, P, B, L, n, dp, flags, None)
+
+    bad = [
+        (fwd(flags=2), 'unknown flag'),
+        (fwd(feats=None), 'bad arguments'),
+        (fwd(x=None), 'bad arguments'),             # neither x nor x_soft
+        (fwd(n=0), 'bad arguments'),
+        (fwd(dilations=None), 'bad arguments'),
+        (fwd(L=0), 'bad shape'),
+        (fwd(B=-1), 'bad shape'),
+        (bwd(flags=4), 'unknown flag'),
+        (bwd(dlogits=None), 'bad arguments'),
+        (bwd(slots=3), 'dcs'),
+        (bwd(slots=2), 'dcs'),                      # two slots only without parameter-gradient partials
+        (bwd(acc=None), 'come together'),
+        (bwd(stem_db=None), 'come together'),
+        (bwd(L=-3), 'bad shape'),
+        (('drk_train_fwd_fused_bf16', P, P, P, P, P, P, P, P, P, P, 2, 225, 20, dp, None), 'L <= 224'),
+        (('drk_train_fwd_fused_bf16', P, P, P, P, P, P, P, P, P, P, 2, 200, 21, dp, None), 'L <= 224'),
+        (('drk_train_fwd_fused_bf16', P, P, P, P, None, P, P, P, P, P, 2, 200, 20, dp, None), 'null pointer'),
+        (('drk_train_fwd_fused_bf16', P, P, P, P, P + 4, P, P, P, P, P, 2, 200, 20, dp, None), 'aligned'),
+        (('drk_train_bwd_fused_bf16', P, P, P, P, P, P, P, P, P, 21, P, None, 0, 2, 512, 20, dp, None), 'L <= 224'),
+        (('drk_train_bwd_fused_bf16', P, P, P, P, P, P, P, P, P, 5, P, None, 0, 2, 200, 20, dp, None), 'dcs_slots'),
+        (('drk_train_bwd_fused_bf16', P, P, P, P, P, P, P, P, P, 21, P, P, 512, 2, 200, 20, dp, None), 'partials'),
+        (('drk_layer_bwd_bf16', P, P, None, None, None, None, None, P, P, P, None, None, 0, 2, 200, 9, 1, 0, None), 'come together'),
+        (('drk_layer_bwd_bf16', P, P, None, None, None, None, None, P, P, P, P, None, 0, 2, 200, 9, 1, 0, None), 'distinct'),
+        (('drk_layer_bwd_bf16', P, P, None, None, None, None, None, P, P, None, None, None, 0, 2, 200, 9, 1, 1, None), 'ln = 1'),
+        (('drk_layer_bwd_bf16', P, P, None, None, None, None, None, P, P, None, None, None, 0, 2, 200, 4, 1, 0, None), 'bad arguments'),
+        (('drk_layer_bwd_bf16', P, P, None, None, None, None, None, P, P, None, None, P, 256, 2, 200, 9, 1, 0, None), 'partials'),
+        (('drk_head_bwd_bf16', P, P, P, P, P, 512, 2, 200, None), '776'),
+        (('drk_head_bwd_bf16', P, P, None, P, None, 0, 2, 200, None), 'bad arguments'),
+        (('drk_conv_wgrad_bf16_multi', P, P, -1, P, 2, 200, 9, 1, P, 1 << 40, None), 'bad arguments'),
+        (('drk_conv_wgrad_bf16_multi', P, P, 3, P, 2, 200, 11, 1, P, 1 << 40, None), 'bad arguments'),
+        (('drk_conv_wgrad_bf16_multi', P, P, 3, P, 2, 200, 9, 1, P, 16, None), 'workspace'),
+        (('drk_conv_wgrad_bf16_multi', P, P, 3, P, 2, 200, 9, 1, P + 8, 1 << 40, None), 'workspace'),
+        (('drk_slab_reduce', P, 4, 512, P, 510, None), 'n % 4'),
+        (('drk_slab_reduce', P, 4, 510, P, 512, None), 'stride % 4'),
+        (('drk_slab_reduce2', P, 40, 512, P, 512, None, None), 'tmp given'),
+        (('drk_slab_reduce2', P + 4, 40, 512, P, 512, P, None), 'aligned'),
+    ]
+    for call, needle in bad:
+        with pytest.raises(_lib.DrakesHipError, match=re.escape(needle)):
+            _lib.call(*call)
+    # an empty batch is a no-op of the whole sequence, not an error
+    _lib.call(*fwd(B=0))
+    _lib.call(*bwd(B=0))
+    _lib.call('drk_conv_wgrad_bf16_multi', P, P, 0, P, 2, 200, 9, 1, P, 0, None)       # no recorded pairs: nothing to add
+    # size queries: 0 for shapes that hold nothing; the fused layouts only within the fused kernels' limits
+    assert lib.drk_denoiser_feats_floats(0, 200, 20, 0) == 0 and lib.drk_denoiser_masks_bytes(4, 200, 0, 0) == 0
+    assert lib.drk_denoiser_is_fused(200, 20, 0) == 1 and lib.drk_denoiser_is_fused(225, 20, 0) == 0
+    assert lib.drk_denoiser_is_fused(200, 21, 0) == 0 and lib.drk_denoiser_is_fused(200, 20, ops.denoiser_flags(True)) == 0
+    assert lib.drk_denoiser_feats_floats(4, 512, 20, 0) == 21 * 4 * 512 * 128
+    assert lib.drk_denoiser_feats_floats(4, 200, 20, 0) == 4 * 200 * 128 + lib.drk_train_fused_featn_floats(4, 20)
+    assert lib.drk_denoiser_masks_bytes(4, 200, 20, ops.denoiser_flags(True)) == 20 * 4 * 200 * 128
+    assert lib.drk_denoiser_bwd_bf16_slab_floats(20) == 21 * 512 + lib.drk_head_bwd_bf16_slab_floats()
+    assert lib.drk_denoiser_bwd_bf16_slabs(128, 200) == 256 + 16 + 1 and lib.drk_denoiser_bwd_bf16_slabs(2, 4096) == 64 + 4 + 1
