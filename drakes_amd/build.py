@@ -26,6 +26,7 @@ SOURCES = {
     'drk_conv_x3.hip': ['-ffp-contract=off'],
     'drk_train_chain.hip': ['-ffp-contract=off'],
     'drk_train_fused_bf16.hip': ['-ffp-contract=off'],
+    'drk_group_bf16.hip': ['-ffp-contract=off'],
 }
 COMMON = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function']
 

@@ -15,8 +15,16 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 #define ROWB 272                 // bytes per h-image row: 128 bf16 + 16 B pad (bank slot = (row + chunk) mod 16); a
                                  // k-step is an IMMEDIATE offset (+16 B) from a per-lane row address: no address VALU
+// The image geometry below is the sampler's and the fused train kernels' (one 200-bp sequence per workgroup);
+// drk_group_bf16.hip (256-row images of long sequences) sets ZROW and DRK_LIVE_END before including this file and
+// keeps its own LDS map behind the image.
 #define MAXPOS 224               // 14 position tiles of 16
-#define ZROW 224                 // the all-zero row of the h image
+#ifndef ZROW
+#define ZROW 224                 // the all-zero row of the h image (also the image's last row)
+#endif
+#ifndef DRK_LIVE_END
+#define DRK_LIVE_END 208         // static live ranges: rows at and beyond this one are padding
+#endif
 #define TAP_BYTES 32768          // one tap of one layer in the fragment stream: [4 k-steps][4 ct][2 s][64 lanes][16 B]
 #define KSTEP_BYTES 8192
 #define SUB_BYTES 1024
@@ -184,7 +192,7 @@ __host__ __device__ constexpr int live_lo(int off, int grp, int nt) {   // first
 }
 __host__ __device__ constexpr int live_hi(int off, int grp, int nt) {   // one past the last live t
   int t = nt;
-  while (t > 0 && off > 0 && 16 * (grp + 2 * (t - 1)) + off >= 208) --t;
+  while (t > 0 && off > 0 && 16 * (grp + 2 * (t - 1)) + off >= DRK_LIVE_END) --t;
   return t < live_lo(off, grp, nt) ? live_lo(off, grp, nt) : t;
 }
 
@@ -279,7 +287,7 @@ __device__ __forceinline__ void static_layer(const char* smem, const char* wn, c
   constexpr int T0 = live_lo(-M * D, GRP, NT), T1 = live_hi(-M * D, GRP, NT);
   // taps beyond +-M must have no live tile for this wave (the caller skips them, weights included)
   static_assert(M == 4 || (live_lo(-(M + 1) * D, GRP, NT) >= live_hi(-(M + 1) * D, GRP, NT) &&
-                           live_lo((M + 1) * D, GRP, NT) >= live_hi((M + 1) * D, GRP, NT)) || (M + 1) * D >= 208,
+                           live_lo((M + 1) * D, GRP, NT) >= live_hi((M + 1) * D, GRP, NT)) || (M + 1) * D >= DRK_LIVE_END,
                 "skipped taps must be dead");
   const char* hb = pad_base(smem, lane);
   bf16v8 cur[NT];

@@ -177,8 +177,9 @@ class Diffusion(nn.Module):
             from . import fastpath
             if L <= fastpath.MAX_L:
                 return fastpath.sample_bf16(self, x, table, float(sigma_last), seed, sample_offset, uniforms)
-            # longer sequences do not fit one workgroup's LDS: one bf16-MFMA launch per residual layer, same step kernels
-            fwd = lambda seq, tb, stride, work: fastpath.forward_bf16_layers(bb, seq, tb, stride, work)
+            # longer sequences do not fit one workgroup's LDS: several residual layers per launch on 256-row images
+            # (or one launch per layer where the shape does not fill them), same step kernels
+            fwd = lambda seq, tb, stride, work: fastpath.forward_bf16_long(bb, seq, tb, stride, work)
         shared = None if self.time_conditioning else self._shared_time_bias(0.0)
         if self.hip_graph and uniforms is None and shared is not None and num_steps > 0:
             x = self._sample_graph(x, table, shared, seed, sample_offset, fwd)
@@ -265,7 +266,7 @@ class Diffusion(nn.Module):
         fwd = bb.forward_x3 if self.hip_dtype == 'bf16x3' else bb.forward_f32
         if self.hip_dtype == 'bf16':       # batched forwards on the bf16 layer kernels (logits within the bf16 bar)
             from . import fastpath
-            fwd = lambda seq, tb, stride, work: fastpath.forward_bf16_layers(bb, seq, tb, stride, work)
+            fwd = lambda seq, tb, stride, work: fastpath.forward_bf16_long(bb, seq, tb, stride, work)
         shared = None if self.time_conditioning else self._shared_time_bias(0.0)
         total = torch.zeros(B, dtype=torch.float32, device=x0.device)
         acc = torch.empty(B, L, dtype=torch.float32, device=x0.device)

@@ -281,6 +281,103 @@ def forward_bf16_layers(bb, seq, tbias, tb_stride, work=None):
     return logits
 
 
+# ---- several layers per launch (drk_layer_group_bf16): long sequences ---------------------------------------------------
+GROUP_HALO_LAYERS = 2      # dilation-1 layers per launch in halo mode (4 recomputed rows per layer and side)
+GROUP_HALO_TILES = 14      # image rows / 16 in halo mode: 14 -> 208 written rows per workgroup with two layers
+GROUP_MIN_FILL = 0.6       # the dispatcher below takes the groups when a stride-mode image is at least this full
+
+
+def group_plan(bb, L, halo_layers=None, halo_tiles=None):
+    """How the residual stack splits into drk_layer_group_bf16 launches for length L: a list of
+    (first_layer, n, stride, tiles16), or None when some layer fits neither mode.  Runs of dilation-1 layers go `halo_layers`
+    at a time with a recomputed halo; a layer of dilation d > 1 opens a stride-d group that takes every following layer
+    whose dilation is d x {1..4, 16} (the rows of one residue class mod d are closed under all of their shifts)."""
+    hl = halo_layers or GROUP_HALO_LAYERS
+    ht = halo_tiles or GROUP_HALO_TILES
+    dil = [bb.dilation(i) for i in range(bb.num_layers)]
+    plan, i, n = [], 0, len(dil)
+    while i < n:
+        d = dil[i]
+        if d == 1:
+            k = i
+            while k < n and k - i < hl and dil[k] == 1:
+                k += 1
+            if _lib.load().drk_layer_group_bf16_rows(k - i, ht) <= 0:
+                return None
+            plan.append((i, k - i, 1, ht))
+        else:
+            if -(-L // d) > 256:
+                return None
+            k = i
+            while k < n and k - i < 12 and dil[k] % d == 0 and (dil[k] // d in (1, 2, 3, 4, 16)):
+                k += 1
+            plan.append((i, k - i, d, 16))
+        i = k
+    return plan
+
+
+def forward_bf16_groups(bb, seq, tbias, work=None, plan=None):
+    """Raw logits [B,L,5] as forward_bf16_layers gives them (same rounding points), with the residual layers run several
+    per launch (drk_layer_group_bf16, csrc/drk_group_bf16.hip): only the fp32 residual stream passes through HBM between
+    launches.  tbias [1, n_layers, 128]: one time for the batch."""
+    pk, st = bb.packed(), _packed(bb)
+    B, L = seq.shape[0], seq.shape[1]
+    n = bb.num_layers
+    if plan is None:
+        plan = group_plan(bb, L)
+    if plan is None:
+        raise NotImplementedError(f'no group plan for length {L} with these dilations: use forward_bf16_layers')
+    if tbias.shape[0] != 1:
+        raise NotImplementedError('drk_layer_group_bf16 takes one time for the batch: use forward_bf16_layers')
+    if work is None:
+        work = {}
+    def buf(name, dtype, *shape):
+        t = work.get(name)
+        if t is None or t.shape != torch.Size(shape) or t.dtype != dtype:
+            t = torch.empty(*shape, dtype=dtype, device=seq.device)
+            work[name] = t
+        return t
+    fp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    feat = [buf('feat', torch.float32, B, L, ops.C), buf('feat1', torch.float32, B, L, ops.C)]
+    h = buf('h0', torch.bfloat16, B, L, ops.C)
+    ops.stem_fwd(seq, pk['stem_w'], pk['stem_b'], out=feat[0])
+    tb = tbias[0].contiguous()
+    cur = 0
+    for gi, (l0, ng, stride, tiles16) in enumerate(plan):
+        last = gi + 1 == len(plan)
+        dst = cur if stride > 1 else cur ^ 1                      # stride mode works in place
+        dil = (ctypes.c_int * ng)(*[bb.dilation(l0 + k) for k in range(ng)])
+        args = (fp(feat[cur]), fp(feat[dst]), _bf16_ptr(h, 'h') if last else None, fp(st['wstream']), fp(st['vecs']), fp(tb), B, L,
+                l0, ng, stride, tiles16, dil, ops._stream())
+        ops.PROFILE.bracket('k_group_bf16', 2.0 * B * L * 9 * ops.C * ops.C * ng, lambda: _lib.call('drk_layer_group_bf16', *args))
+        cur = dst
+    work['feat_final'] = feat[cur]
+    logits = buf('logits', torch.float32, B, L, ops.V)
+    _lib.call('drk_head_bf16', _bf16_ptr(h, 'h'), fp(st['wstream'][9 * n:]), fp(st['vecs'][3 * n + 1]), fp(pk['head2_w']),
+              fp(pk['head2_b']), fp(logits), B, L, ops._stream())
+    return logits
+
+
+def forward_bf16_long(bb, seq, tbias, tb_stride, work=None):
+    """The bf16 forward for sequences beyond the fused sampler: several layers per launch where the shape fills the
+    group kernel's images (one time for the batch, ceil(L / stride) of 256 rows at least GROUP_MIN_FILL), else one launch
+    per layer."""
+    L = seq.shape[1]
+    if tb_stride == 0 and tbias.shape[0] == 1 and getattr(bb, 'width', 128) == 128:
+        key = (L, tuple(bb.dilation(i) for i in range(bb.num_layers)))
+        cache = getattr(bb, '_group_plans', None)
+        if cache is None:
+            cache = bb._group_plans = {}
+        if key not in cache:
+            plan = group_plan(bb, L)
+            if plan is not None and any(s > 1 and -(-L // s) < GROUP_MIN_FILL * 256 for _, _, s, _ in plan):
+                plan = None
+            cache[key] = plan
+        if cache[key] is not None:
+            return forward_bf16_groups(bb, seq, tbias, work, cache[key])
+    return forward_bf16_layers(bb, seq, tbias, tb_stride, work)
+
+
 # ---- the fused train kernels' lane-order saved blocks, mapped back onto rows (tests, gate logging) ----------------------
 FEATN_SEQ = 8 * 14 * 256      # floats per sequence and layer in featn (drk_train_fused_bf16.hip)
 MASKP_SEQ = 8 * 64            # uint64 per sequence and layer in maskp

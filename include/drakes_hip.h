@@ -290,6 +290,23 @@ int drk_stem_ln_bf16(const int64_t* x, const float* w_t, const float* bias, cons
  * chip; the bits are those of drk_layer_bf16(taps = 1, relu = 1) followed by drk_head_out_fwd. */
 int drk_head_bf16(const void* h, const void* wfrag, const float* bias, const float* head_w, const float* head_b,
                   float* logits, int B, int L, void* stream);
+/* SEVERAL consecutive residual layers (models/dnaconv.py:88-101, dilations dnaconv.py:53-58) in one launch, for
+ * sequences beyond the fused sampler's 224 positions: layers first_layer .. first_layer + n_group - 1 applied to the
+ * float32 residual stream feat_in [B*L][128] -> feat_out, every workgroup keeping a 256-row image on the chip for the
+ * whole group (csrc/drk_group_bf16.hip).  Same rounding points as drk_layer_bf16 run layer by layer.
+ *   stride > 1: the rows of one residue class (position mod stride) of one sequence per workgroup; every dilation a
+ *               multiple of stride, dilation / stride in {1..4, 16}, ceil(L / stride) <= 256, tiles16 = 16; feat_out
+ *               may be feat_in.
+ *   stride = 1: consecutive rows with a recomputed halo of 4 * (sum of the dilations) rows either side; dilations in
+ *               1..4; tiles16 = 14 or 16 (image rows / 16); feat_out != feat_in.
+ * wstream, vecs, tbias: the whole model's fragment stream, vector table and time biases [n_layers][128] (one row for
+ * the batch) as drk_sample_bf16 takes them; dilations: the group's n_group true dilations.  h_out: NULL, or bf16
+ * [B*L][128] = bf16(feat_out), the operand of drk_head_bf16. */
+int drk_layer_group_bf16(const float* feat_in, float* feat_out, void* h_out, const void* wstream, const float* vecs,
+                         const float* tbias, int B, int L, int first_layer, int n_group, int stride, int tiles16,
+                         const int* dilations, void* stream);
+/* Rows of feat_out one workgroup of drk_layer_group_bf16 writes at stride = 1 (0: the group does not fit the image). */
+long drk_layer_group_bf16_rows(int n_group, int tiles16);
 
 /* ---- bf16 backward of the denoiser (the differentiable bf16 path; reference: torch autograd over
  * models/dnaconv.py:88-101 inside _sample_finetune_gradient, diffusion_gosai_update.py:589-630) ----------------------

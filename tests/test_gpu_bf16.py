@@ -9,13 +9,15 @@ other conv zeroed, the residual stream after the layer under test must match the
 1e-3 (one flip ~ 2e-4), for each of the four dilations, and the stem must match exactly.
 Integer bar: given the kernel's own logits, the fused reverse step must reproduce the oracle's
 tokens bit-exactly."""
+import re
+
 import numpy as np
 import pytest
 import torch
 
 import drakes_amd
 from conftest import load_golden
-from drakes_amd import fastpath, ops
+from drakes_amd import _lib, fastpath, ops
 from oracle import bf16_emulation as E
 from oracle import drakes_oracle as O
 from oracle import philox
@@ -243,6 +245,104 @@ def test_layer_path_single_layer_tight(dev, det_sd, layer):
     err = (got - want).abs()
     print(f'layer {layer}: max {err.max().item():.2e} rms {err.pow(2).mean().sqrt().item():.2e}')
     assert err.max().item() < 1e-3 and err.pow(2).mean().sqrt().item() < 5e-5
+
+
+# ---- several layers per launch (drk_layer_group_bf16): 256-row images of long sequences -----------------------------------
+@pytest.mark.parametrize('B,L', [(2, 1024), (3, 1000), (2, 1021), (1, 300), (2, 640), (1, 229)])
+def test_group_path_logits(gpu_model, dev, det_sd, B, L):
+    """The layer path's bar (6e-2 max / 1e-2 rms to fp32 and to the emulation) for the grouped launches: stride-4 images
+    of the twelve dilation-4/16/64 layers (full at L = 1024, ragged residue classes at 1021 and 1000, mostly padding at
+    300), halo images of the dilation-1 layers whose last tile is partial; and close to the layer path itself."""
+    gen = np.random.Generator(np.random.PCG64(300 + L))
+    x = torch.from_numpy(gen.integers(0, 5, (B, L)))
+    x[0] = 4
+    with torch.no_grad():
+        emu = E.cnn_forward_bf16(det_sd, x, torch.zeros(B)).numpy()
+        ref = O.cnn_forward(det_sd, x, torch.zeros(B)).numpy()
+    bb = gpu_model.backbone
+    tbias = bb.time_bias(torch.zeros(1, device=dev))
+    assert fastpath.group_plan(bb, L) == [(0, 2, 1, 14), (2, 2, 1, 14), (4, 2, 1, 14), (6, 2, 1, 14), (8, 12, 4, 16)]
+    got = fastpath.forward_bf16_groups(bb, x.to(dev), tbias).cpu().numpy()
+    lay = fastpath.forward_bf16_layers(bb, x.to(dev), tbias, 0).cpu().numpy()
+    print(f'L={L}: max|groups-emulation|={np.abs(got - emu).max():.2e}  max|groups-fp32|={np.abs(got - ref).max():.2e}  '
+          f'rms|groups-layers|={np.sqrt(((got - lay) ** 2).mean()):.2e}')
+    np.testing.assert_allclose(got, ref, rtol=0, atol=6e-2)
+    assert np.sqrt(((got - ref) ** 2).mean()) < 1e-2
+    assert np.sqrt(((got - emu) ** 2).mean()) < 1e-2
+    assert np.sqrt(((got - lay) ** 2).mean()) < 5e-3
+
+
+@pytest.mark.parametrize('layer,L', [(0, 300), (7, 300), (8, 300), (12, 300), (16, 300), (19, 300), (3, 1024), (9, 1024),
+                                     (13, 1024), (18, 1024), (17, 1021)])
+def test_group_path_single_layer_tight(dev, det_sd, layer, L):
+    """All convs except `layer` zeroed: the residual stream the grouped launches leave must match the emulation of
+    stem + that layer to 1e-3, for every dilation and both image modes (sequence ends, tile seams, ragged residue
+    classes)."""
+    import torch.nn.functional as F
+    sd = {k: v.clone() for k, v in det_sd.items()}
+    for i in range(20):
+        if i != layer:
+            sd[f'backbone.convs.{i}.weight'].zero_()
+            sd[f'backbone.convs.{i}.bias'].zero_()
+    m = drakes_amd.Diffusion(drakes_amd.default_config(length=L)).to(dev)
+    m.load_state_dict(sd)
+    gen = np.random.Generator(np.random.PCG64(18))
+    B = 2
+    x = torch.from_numpy(gen.integers(0, 5, (B, L)))
+    x[0] = 4
+    sigma = torch.tensor([1.1])
+    tbias = m.backbone.time_bias(sigma.to(dev))
+    work = {}
+    fastpath.forward_bf16_groups(m.backbone, x.to(dev), tbias, work)
+    got = work['feat_final'].cpu()
+    with torch.no_grad():
+        f0 = F.relu(F.conv1d(F.one_hot(x, 5).float().permute(0, 2, 1), sd['backbone.linear.weight'],
+                             sd['backbone.linear.bias'], padding=4))
+        d = O.layer_dilation(layer, 20)
+        temb = O.time_embedding(sd, sigma)
+        tb = F.linear(temb, sd[f'backbone.time_layers.{layer}.dense.weight'], sd[f'backbone.time_layers.{layer}.dense.bias'])
+        h = F.layer_norm((f0 + tb[:, :, None]).permute(0, 2, 1), (128,), sd[f'backbone.norms.{layer}.weight'],
+                         sd[f'backbone.norms.{layer}.bias'])
+        c = F.relu(F.conv1d(E.r16(h).permute(0, 2, 1), E.r16(sd[f'backbone.convs.{layer}.weight']),
+                            sd[f'backbone.convs.{layer}.bias'], dilation=d, padding=4 * d))
+        want = (c + f0).permute(0, 2, 1)
+    err = (got - want).abs()
+    print(f'layer {layer} L {L}: max {err.max().item():.2e} rms {err.pow(2).mean().sqrt().item():.2e}')
+    assert err.max().item() < 1e-3 and err.pow(2).mean().sqrt().item() < 5e-5
+
+
+def test_group_plans_agree_bitwise(gpu_model, dev):
+    """A row's arithmetic does not depend on the image it is computed in: other splits of the dilation-1 layers (one,
+    two or four a launch, 224- or 256-row images) and of the stride-4 layers give the same bits."""
+    bb = gpu_model.backbone
+    B, L = 2, 1000
+    gen = np.random.Generator(np.random.PCG64(77))
+    x = torch.from_numpy(gen.integers(0, 5, (B, L))).to(dev)
+    tbias = bb.time_bias(torch.full((1,), 0.7, device=dev))
+    base = fastpath.forward_bf16_groups(bb, x, tbias).clone()
+    for hl, ht in [(1, 14), (2, 16), (4, 16), (8, 16), (3, 14)]:
+        plan = fastpath.group_plan(bb, L, hl, ht)
+        assert torch.equal(fastpath.forward_bf16_groups(bb, x, tbias, None, plan), base), (hl, ht)
+    split = [(0, 2, 1, 14), (2, 2, 1, 14), (4, 2, 1, 14), (6, 2, 1, 14), (8, 4, 4, 16), (12, 5, 4, 16), (17, 3, 4, 16)]
+    assert torch.equal(fastpath.forward_bf16_groups(bb, x, tbias, None, split), base)
+    split = [(0, 4, 1, 16), (4, 4, 1, 16), (8, 4, 4, 16), (12, 4, 16, 16), (16, 4, 64, 16)]      # stride = the dilation itself
+    assert torch.equal(fastpath.forward_bf16_groups(bb, x, tbias, None, split), base)
+    split = [(0, 3, 1, 16), (3, 5, 1, 16), (8, 2, 1, 16), (10, 10, 4, 16)]      # dilation 4 with a halo of 32 rows
+    assert torch.equal(fastpath.forward_bf16_groups(bb, x, tbias, None, split), base)
+
+
+def test_group_entry_point_rejects_what_it_cannot_run(gpu_model, dev):
+    bb = gpu_model.backbone
+    x = torch.zeros(1, 2048, dtype=torch.int64, device=dev)
+    tbias = bb.time_bias(torch.zeros(1, device=dev))
+    assert fastpath.group_plan(bb, 2048) is None                       # 512 rows per residue class mod 4
+    for plan, needle in [([(8, 4, 4, 16)], 'ceil(L / stride) <= 256'), ([(8, 4, 3, 16)], 'multiple of stride'),
+                         ([(0, 13, 1, 16)], '1..12 layers'), ([(12, 4, 1, 16)], 'dilation / stride'),
+                         ([(0, 2, 1, 12)], 'tiles16')]:
+        with pytest.raises(_lib.DrakesHipError, match=re.escape(needle)):
+            fastpath.forward_bf16_groups(bb, x, tbias, None, plan)
+    with pytest.raises(NotImplementedError):
+        fastpath.forward_bf16_groups(bb, x[:, :1024].repeat(2, 1), bb.time_bias(torch.tensor([0.1, 0.2], device=dev)))
 
 
 def test_long_sequences_take_the_layer_path(dev, det_sd):

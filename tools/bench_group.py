@@ -1,0 +1,65 @@
+"""Times the bf16 forward of a long batch (BASELINE.json configs[4]: B=256, L=1024) launch by launch: the grouped
+launches (drk_layer_group_bf16) under several plans against one launch per layer.  python tools/bench_group.py [B] [L]"""
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import drakes_amd
+from drakes_amd import fastpath, ops
+from drakes_amd.det_init import det_state_dict
+
+
+def timed(fn, reps=10):
+    fn(); fn()
+    torch.cuda.synchronize()
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0.record()
+    for _ in range(reps):
+        fn()
+    t1.record()
+    torch.cuda.synchronize()
+    return t0.elapsed_time(t1) / reps * 1e3     # us
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+    L = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+    dev = torch.device('cuda:0')
+    m = drakes_amd.Diffusion(drakes_amd.default_config(length=L)).to(dev)
+    m.load_state_dict(det_state_dict(0))
+    bb = m.backbone
+    x = torch.randint(0, 4, (B, L), device=dev)
+    x[:, ::3] = 4
+    tbias = bb.time_bias(torch.zeros(1, device=dev))
+    out = {'B': B, 'L': L, 'drk_version': drakes_amd._lib.load().drk_version()}
+    work = {}
+    out['layers_us'] = timed(lambda: fastpath.forward_bf16_layers(bb, x, tbias, 0, work))
+    plans = {'h2x14': fastpath.group_plan(bb, L, 2, 14), 'h4x16': fastpath.group_plan(bb, L, 4, 16),
+             'h1x14': fastpath.group_plan(bb, L, 1, 14), 'h8x16': fastpath.group_plan(bb, L, 8, 16)}
+    for name, plan in plans.items():
+        w2 = {}
+        out[f'groups_{name}_us'] = timed(lambda: fastpath.forward_bf16_groups(bb, x, tbias, w2, plan))
+        # launch by launch
+        per = []
+        for g in plan:
+            # just this group on whatever the buffers hold (timing only: the values do not matter)
+            pk, st = bb.packed(), fastpath._packed(bb)
+            import ctypes
+            fp = lambda t: ctypes.c_void_p(t.data_ptr())
+            fa, fb = w2['feat'], w2['feat1']
+            l0, ng, stride, tiles16 = g
+            dil = (ctypes.c_int * ng)(*[bb.dilation(l0 + k) for k in range(ng)])
+            tb = tbias[0].contiguous()
+            args = (fp(fa), fp(fa if stride > 1 else fb), None, fp(st['wstream']), fp(st['vecs']), fp(tb), B, L, l0, ng, stride,
+                    tiles16, dil, ops._stream())
+            per.append((g, round(timed(lambda: drakes_amd._lib.call('drk_layer_group_bf16', *args)), 1)))
+        out[f'groups_{name}_launches'] = per
+    print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()
