@@ -288,8 +288,41 @@ def _time_layer_kernel(model, B, Ll, reps=20):
     return 'k_layer_bf16 (one residual layer, timed alone after the run)', reps, ms, 2.0 * B * Ll * 9 * 128 * 128
 
 
+def _time_group_kernels(model, B, Ll, reps=10):
+    """Every launch of the grouped long-sequence forward (drk_layer_group_bf16) timed alone after the run, same shapes,
+    HIP events on its stream.  Returns [(plan entry, ms, dense FLOP)], or None when the shape takes the layer path."""
+    import ctypes
+    from drakes_amd import _lib, fastpath, ops
+    bb = model.backbone
+    plan = fastpath.group_plan(bb, Ll)
+    if plan is None:
+        return None
+    st = fastpath._packed(bb)
+    dev = next(bb.parameters()).device
+    fa = torch.randn(B, Ll, 128, device=dev)
+    fb = torch.empty_like(fa)
+    tb = bb.time_bias(torch.zeros(1, device=dev))[0].contiguous()
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    out = []
+    for (l0, ng, stride, tiles16) in plan:
+        dil = (ctypes.c_int * ng)(*[bb.dilation(l0 + k) for k in range(ng)])
+        a = (P(fa), P(fa if stride > 1 else fb), None, P(st['wstream']), P(st['vecs']), P(tb), B, Ll, l0, ng, stride, tiles16, dil,
+             ops._stream())
+        for _ in range(2):
+            _lib.call('drk_layer_group_bf16', *a)
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        for s_, e_ in evs:
+            s_.record()
+            _lib.call('drk_layer_group_bf16', *a)
+            e_.record()
+        torch.cuda.synchronize()
+        out.append(((l0, ng, stride, tiles16), sum(s_.elapsed_time(e_) for s_, e_ in evs) / reps, 2.0 * B * Ll * 9 * 128 * 128 * ng))
+    return out
+
+
 def workload_long(args, rank, world, dev, barrier):
-    """configs[4] per GPU: L=1024, 512 steps, bf16 layer kernels (the fused loop holds L <= 224)."""
+    """configs[4] per GPU: L=1024, 512 steps, bf16 kernels for sequences beyond the fused loop's 224 positions: the
+    residual layers several per launch (drk_layer_group_bf16)."""
     import drakes_amd
     from drakes_amd import ops
     Ll, steps, B = 1024, 512, args.batch if args.batch != 1024 else 256
@@ -307,12 +340,25 @@ def workload_long(args, rank, world, dev, barrier):
     elapsed = time.perf_counter() - t0
     name, n, ms, fl = ops.PROFILE.disable()
     rows = B * Ll
-    if not n and args.dtype == 'bf16':
-        # the captured step replays without passing the launch brackets: time the dominant kernel (one residual layer,
-        # dilation 1) on its own after the timed region, same shapes, HIP events on its stream
+    roof = {'bound': 'mfma', 'kernel': name, 'launches_timed': n, 'avg_launch_ms': ms}
+    groups = _time_group_kernels(m, B, Ll) if (not n and args.dtype == 'bf16') else None
+    if groups:
+        # the captured step replays without passing the launch brackets: every launch of the forward timed on its own
+        # after the timed region.  Dominant: the stride-mode launch (the twelve dilation-4/16/64 layers), MFMA-bound:
+        # one launch moves 1 KB per row through HBM for 12 x 295 kFLOP per row
+        g, gms, gfl = max(groups, key=lambda t: t[1])
+        roof = {'bound': 'mfma', 'kernel': f'k_group_bf16 (layers {g[0]}..{g[0] + g[1] - 1}, stride {g[2]}, timed alone after the run)',
+                'launches_timed': 10, 'avg_launch_ms': gms, 'achieved': gfl / gms / 1e9, 'peak': 2500.0, 'unit': 'TFLOP/s',
+                'traffic': None, 'flop_per_row_and_layer': 2 * 9 * 128 * 128,
+                'hbm_GBps': rows * 1024 / (gms * 1e-3) / 1e9,
+                'forward_launches_ms': [[list(e), round(t, 4)] for e, t, _ in groups],
+                'forward_layers_ms_total': sum(t for _, t, _ in groups),
+                'forward_TFLOPs_dense': sum(f for _, _, f in groups) / sum(t for _, t, _ in groups) / 1e9}
+        roof['frac'] = roof['achieved'] / roof['peak']
+    elif not n and args.dtype == 'bf16':
         name, n, ms, fl = _time_layer_kernel(m, B, Ll)
-    roof = {'bound': 'hbm', 'kernel': name, 'launches_timed': n, 'avg_launch_ms': ms}
-    if ms and name and 'layer' in name:
+        roof = {'bound': 'hbm', 'kernel': name, 'launches_timed': n, 'avg_launch_ms': ms}
+    if 'frac' not in roof and ms and name and 'layer' in name:
         per_row = getattr(ops, 'LAYER_BYTES_PER_ROW', 1536)
         roof.update({'achieved': rows * per_row / (ms * 1e-3) / 1e9, 'peak': 8000.0, 'unit': 'GB/s', 'traffic': None,
                      'bytes_per_row': per_row, 'TFLOPs_dense': fl / ms / 1e9})

@@ -34,8 +34,8 @@ struct GroupArgs {
   const float* vecs;        // vector blocks at the group's first layer: [n+1][3][128] (block 0: -, gamma, beta of its LayerNorm)
   const float* tbias;       // [n][128] at the group's first layer, shared by the batch
   const float* feat_in;     // [B][L][128] fp32 residual stream
-  float* feat_out;
-  char* h_out;              // bf16 [B][L][128] of feat_out (final_conv.0's operand), or NULL
+  float* feat_out;          // NULL: not wanted (the stack's last group, whose h_out is all the head reads)
+  char* h_out;              // bf16 [B][L][128] of the outgoing stream (final_conv.0's operand), or NULL
   int B, L, n;
   int stride, halo, T, tiles_per_seq;
   unsigned long long dilpk[2];   // in-image dilations, 8 bits a layer
@@ -198,7 +198,7 @@ __device__ __forceinline__ void group_body(const GroupArgs& a, char* smem, int t
     for (int t = 0; t < NT; ++t) {
       const int k = 16 * (grp + 2 * t) + pn;
       const int p = p0 + a.stride * k;
-      if (((vmask >> t) & 1u) && (unsigned)(k - a.halo) < (unsigned)a.T) {
+      if (a.feat_out && ((vmask >> t) & 1u) && (unsigned)(k - a.halo) < (unsigned)a.T) {
         *(f32x4*)(fo + (long)p * 128) = feat[t][0];
         *(f32x4*)(fo + (long)p * 128 + 16) = feat[t][1];
       }
@@ -245,12 +245,12 @@ extern "C" long drk_layer_group_bf16_rows(int n_group, int tiles16) {
 //   stride = 1: every dilation in 1..4 (halo = 4 x their sum), tiles16 = 14 or 16 (image rows / 16), feat_out != feat_in.
 // wstream / vecs / tbias: the WHOLE model's fragment stream, vector table and time-bias table [n_layers][128] (one time
 // for the batch), as drk_sample_bf16 takes them; dilations: the group's n_group TRUE dilations.  h_out: also leaves
-// bf16(feat_out) as rows (the operand of drk_head_bf16), or NULL.
+// bf16 of the outgoing stream as rows (the operand of drk_head_bf16), or NULL; feat_out may be NULL when h_out is given.
 extern "C" int drk_layer_group_bf16(const float* feat_in, float* feat_out, void* h_out, const void* wstream, const float* vecs,
                                     const float* tbias, int B, int L, int first_layer, int n_group, int stride, int tiles16,
                                     const int* dilations, void* stream) {
   DRK_SHAPE_GUARD("drk_layer_group_bf16");
-  if (!feat_in || !feat_out || !wstream || !vecs || !tbias || !dilations)
+  if (!feat_in || (!feat_out && !h_out) || !wstream || !vecs || !tbias || !dilations)
     return drk_set_error_msg(DRK_EINVAL, "drk_layer_group_bf16: null pointer");
   if (((uintptr_t)feat_in | (uintptr_t)feat_out | (uintptr_t)h_out | (uintptr_t)wstream | (uintptr_t)vecs | (uintptr_t)tbias) & 15)
     return drk_set_error_msg(DRK_EINVAL, "drk_layer_group_bf16: 16-byte aligned pointers");

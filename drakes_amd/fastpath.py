@@ -282,8 +282,9 @@ def forward_bf16_layers(bb, seq, tbias, tb_stride, work=None):
 
 
 # ---- several layers per launch (drk_layer_group_bf16): long sequences ---------------------------------------------------
-GROUP_HALO_LAYERS = 2      # dilation-1 layers per launch in halo mode (4 recomputed rows per layer and side)
-GROUP_HALO_TILES = 14      # image rows / 16 in halo mode: 14 -> 208 written rows per workgroup with two layers
+GROUP_HALO_LAYERS = 4      # dilation-1 layers per launch in halo mode (4 recomputed rows per layer and side)
+GROUP_HALO_TILES = 16      # image rows / 16 in halo mode: 256 rows, 224 of them written with four layers (5 images per
+                           # 1024 rows, as with two layers in 224-row images; half the launches and bytes)
 GROUP_MIN_FILL = 0.6       # the dispatcher below takes the groups when a stride-mode image is at least this full
 
 
@@ -316,10 +317,11 @@ def group_plan(bb, L, halo_layers=None, halo_tiles=None):
     return plan
 
 
-def forward_bf16_groups(bb, seq, tbias, work=None, plan=None):
+def forward_bf16_groups(bb, seq, tbias, work=None, plan=None, keep_feat=False):
     """Raw logits [B,L,5] as forward_bf16_layers gives them (same rounding points), with the residual layers run several
     per launch (drk_layer_group_bf16, csrc/drk_group_bf16.hip): only the fp32 residual stream passes through HBM between
-    launches.  tbias [1, n_layers, 128]: one time for the batch."""
+    launches.  tbias [1, n_layers, 128]: one time for the batch.  keep_feat: the last group also writes its fp32 stream
+    (work['feat_final']; tests), which nothing else reads."""
     pk, st = bb.packed(), _packed(bb)
     B, L = seq.shape[0], seq.shape[1]
     n = bb.num_layers
@@ -347,11 +349,12 @@ def forward_bf16_groups(bb, seq, tbias, work=None, plan=None):
         last = gi + 1 == len(plan)
         dst = cur if stride > 1 else cur ^ 1                      # stride mode works in place
         dil = (ctypes.c_int * ng)(*[bb.dilation(l0 + k) for k in range(ng)])
-        args = (fp(feat[cur]), fp(feat[dst]), _bf16_ptr(h, 'h') if last else None, fp(st['wstream']), fp(st['vecs']), fp(tb), B, L,
+        fout = fp(feat[dst]) if (keep_feat or not last) else None
+        args = (fp(feat[cur]), fout, _bf16_ptr(h, 'h') if last else None, fp(st['wstream']), fp(st['vecs']), fp(tb), B, L,
                 l0, ng, stride, tiles16, dil, ops._stream())
         ops.PROFILE.bracket('k_group_bf16', 2.0 * B * L * 9 * ops.C * ops.C * ng, lambda: _lib.call('drk_layer_group_bf16', *args))
         cur = dst
-    work['feat_final'] = feat[cur]
+    work['feat_final'] = feat[cur] if keep_feat else None
     logits = buf('logits', torch.float32, B, L, ops.V)
     _lib.call('drk_head_bf16', _bf16_ptr(h, 'h'), fp(st['wstream'][9 * n:]), fp(st['vecs'][3 * n + 1]), fp(pk['head2_w']),
               fp(pk['head2_b']), fp(logits), B, L, ops._stream())

@@ -301,7 +301,8 @@ int drk_head_bf16(const void* h, const void* wfrag, const float* bias, const flo
  *               1..4; tiles16 = 14 or 16 (image rows / 16); feat_out != feat_in.
  * wstream, vecs, tbias: the whole model's fragment stream, vector table and time biases [n_layers][128] (one row for
  * the batch) as drk_sample_bf16 takes them; dilations: the group's n_group true dilations.  h_out: NULL, or bf16
- * [B*L][128] = bf16(feat_out), the operand of drk_head_bf16. */
+ * [B*L][128] = bf16 of the outgoing stream, the operand of drk_head_bf16; with h_out given feat_out may be NULL (the
+ * stack's last group: nothing reads its fp32 stream). */
 int drk_layer_group_bf16(const float* feat_in, float* feat_out, void* h_out, const void* wstream, const float* vecs,
                          const float* tbias, int B, int L, int first_layer, int n_group, int stride, int tiles16,
                          const int* dilations, void* stream);

@@ -261,7 +261,7 @@ def test_group_path_logits(gpu_model, dev, det_sd, B, L):
         ref = O.cnn_forward(det_sd, x, torch.zeros(B)).numpy()
     bb = gpu_model.backbone
     tbias = bb.time_bias(torch.zeros(1, device=dev))
-    assert fastpath.group_plan(bb, L) == [(0, 2, 1, 14), (2, 2, 1, 14), (4, 2, 1, 14), (6, 2, 1, 14), (8, 12, 4, 16)]
+    assert fastpath.group_plan(bb, L) == [(0, 4, 1, 16), (4, 4, 1, 16), (8, 12, 4, 16)]
     got = fastpath.forward_bf16_groups(bb, x.to(dev), tbias).cpu().numpy()
     lay = fastpath.forward_bf16_layers(bb, x.to(dev), tbias, 0).cpu().numpy()
     print(f'L={L}: max|groups-emulation|={np.abs(got - emu).max():.2e}  max|groups-fp32|={np.abs(got - ref).max():.2e}  '
@@ -293,7 +293,7 @@ def test_group_path_single_layer_tight(dev, det_sd, layer, L):
     sigma = torch.tensor([1.1])
     tbias = m.backbone.time_bias(sigma.to(dev))
     work = {}
-    fastpath.forward_bf16_groups(m.backbone, x.to(dev), tbias, work)
+    fastpath.forward_bf16_groups(m.backbone, x.to(dev), tbias, work, keep_feat=True)
     got = work['feat_final'].cpu()
     with torch.no_grad():
         f0 = F.relu(F.conv1d(F.one_hot(x, 5).float().permute(0, 2, 1), sd['backbone.linear.weight'],
@@ -320,7 +320,7 @@ def test_group_plans_agree_bitwise(gpu_model, dev):
     x = torch.from_numpy(gen.integers(0, 5, (B, L))).to(dev)
     tbias = bb.time_bias(torch.full((1,), 0.7, device=dev))
     base = fastpath.forward_bf16_groups(bb, x, tbias).clone()
-    for hl, ht in [(1, 14), (2, 16), (4, 16), (8, 16), (3, 14)]:
+    for hl, ht in [(1, 14), (2, 14), (2, 16), (8, 16), (3, 14)]:
         plan = fastpath.group_plan(bb, L, hl, ht)
         assert torch.equal(fastpath.forward_bf16_groups(bb, x, tbias, None, plan), base), (hl, ht)
     split = [(0, 2, 1, 14), (2, 2, 1, 14), (4, 2, 1, 14), (6, 2, 1, 14), (8, 4, 4, 16), (12, 5, 4, 16), (17, 3, 4, 16)]
