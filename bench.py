@@ -289,25 +289,22 @@ def _time_layer_kernel(model, B, Ll, reps=20):
 
 
 def _time_group_kernels(model, B, Ll, reps=10):
-    """Every launch of the grouped long-sequence forward (drk_layer_group_bf16) timed alone after the run, same shapes,
-    HIP events on its stream.  Returns [(plan entry, ms, dense FLOP)], or None when the shape takes the layer path."""
-    import ctypes
-    from drakes_amd import _lib, fastpath, ops
+    """Every launch of the grouped long-sequence forward (drk_layer_group_bf16; the first with the stem, the last with the
+    head) timed alone after the run, same shapes, HIP events on its stream.  Returns [(plan entry, ms, dense FLOP)], or
+    None when the shape takes the layer path."""
+    from drakes_amd import _lib, fastpath
     bb = model.backbone
     plan = fastpath.group_plan(bb, Ll)
     if plan is None:
         return None
-    st = fastpath._packed(bb)
     dev = next(bb.parameters()).device
-    fa = torch.randn(B, Ll, 128, device=dev)
-    fb = torch.empty_like(fa)
-    tb = bb.time_bias(torch.zeros(1, device=dev))[0].contiguous()
-    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    x = torch.randint(0, 5, (B, Ll), device=dev)
+    work = {}
+    tbias = bb.time_bias(torch.zeros(1, device=dev))
+    fastpath.forward_bf16_groups(bb, x, tbias, work, plan)            # fills the buffers with a real forward's values
+    launches, _, _ = fastpath.group_launches(bb, x, tbias, work, plan)
     out = []
-    for (l0, ng, stride, tiles16) in plan:
-        dil = (ctypes.c_int * ng)(*[bb.dilation(l0 + k) for k in range(ng)])
-        a = (P(fa), P(fa if stride > 1 else fb), None, P(st['wstream']), P(st['vecs']), P(tb), B, Ll, l0, ng, stride, tiles16, dil,
-             ops._stream())
+    for entry, a in launches:
         for _ in range(2):
             _lib.call('drk_layer_group_bf16', *a)
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
@@ -316,7 +313,7 @@ def _time_group_kernels(model, B, Ll, reps=10):
             _lib.call('drk_layer_group_bf16', *a)
             e_.record()
         torch.cuda.synchronize()
-        out.append(((l0, ng, stride, tiles16), sum(s_.elapsed_time(e_) for s_, e_ in evs) / reps, 2.0 * B * Ll * 9 * 128 * 128 * ng))
+        out.append((entry, sum(s_.elapsed_time(e_) for s_, e_ in evs) / reps, 2.0 * B * Ll * 9 * 128 * 128 * entry[1]))
     return out
 
 

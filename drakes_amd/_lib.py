@@ -67,7 +67,7 @@ SIGNATURES = {
     'drk_train_fwd_fused_bf16': [_P] * 10 + [c_int, c_int, c_int, _P, _P],
     'drk_denoiser_bwd_bf16': [_P] * 11 + [c_int] + [_P] * 9 + [c_int, c_int, c_int, _P, c_int, _P],
     'drk_train_bwd_fused_bf16': [_P] * 9 + [c_int, _P, _P, c_long, c_int, c_int, c_int, _P, _P],
-    'drk_layer_group_bf16': [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P],
+    'drk_layer_group_bf16': [_P] * 12 + [c_int, c_int, c_int, c_int, c_int, c_int, _P, _P],
     'drk_sample_bf16': [_P, _P, _P, _P, _P, c_long, _P, _P, _P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, c_int,
                         c_uint64, c_uint64, c_int, _P],
 }

@@ -27,15 +27,24 @@
 #define G_OFF_PART G_IMG_BYTES                                    // float [256][12]: LayerNorm partials
 #define G_OFF_VECS (G_OFF_PART + G_ROWS * PART_STRIDE * 4)        // float [n+1][3][128]: blocks first_layer .. first_layer + n
 #define G_OFF_TB (G_OFF_VECS + (G_MAX_LAYERS + 1) * 3 * 128 * 4)  // float [n][128]
-#define G_LDS_BYTES (G_OFF_TB + G_MAX_LAYERS * 128 * 4)           // 116 736
+#define G_OFF_STEMW (G_OFF_TB + G_MAX_LAYERS * 128 * 4)           // float [9][5][128]: the stem's weights (token input only)
+#define G_OFF_TOKS (G_OFF_STEMW + 9 * 5 * 128 * 4)                // int [256 + 8]: tokens of image rows -4 .. 259
+#define G_LDS_BYTES (G_OFF_TOKS + (G_ROWS + 8) * 4)               // 140 832
+#define G_STG_STRIDE 132                                          // floats per row of the head's fp32 staging tile [128][132]
 
 struct GroupArgs {
   const char* wfrag;        // fragment stream at the group's first layer (fastpath.py::pack_stream)
   const float* vecs;        // vector blocks at the group's first layer: [n+1][3][128] (block 0: -, gamma, beta of its LayerNorm)
   const float* tbias;       // [n][128] at the group's first layer, shared by the batch
-  const float* feat_in;     // [B][L][128] fp32 residual stream
+  const float* feat_in;     // [B][L][128] fp32 residual stream; NULL with x_tok
+  const int64_t* x_tok;     // [B][L] tokens: the stem (dnaconv.py:80-86) runs here, k_stem_tok's arithmetic (halo mode only)
+  const float* stem_w;      // [9][5][128]
+  const float* stem_b;      // [128]
   float* feat_out;          // NULL: not wanted (the stack's last group, whose h_out is all the head reads)
   char* h_out;              // bf16 [B][L][128] of the outgoing stream (final_conv.0's operand), or NULL
+  float* logits;            // [B][L][5]: the head (dnaconv.py:60-63, 103-104) runs here, drk_head_bf16's arithmetic; or NULL
+  const float* head_w;      // [5][128]
+  const float* head_b;      // [5]
   int B, L, n;
   int stride, halo, T, tiles_per_seq;
   unsigned long long dilpk[2];   // in-image dilations, 8 bits a layer
@@ -131,19 +140,58 @@ __device__ __forceinline__ void group_body(const GroupArgs& a, char* smem, int t
 
   f32x4 feat[NT][2], acc[NT][2];
   unsigned vmask = 0;
+  if (a.x_tok) {   // (uniform) tokens in: the stem's weights and this image's tokens go to LDS first
+    for (int i = tid; i < 9 * 5 * 128 / 4; i += 512) ((f32x4*)(smem + G_OFF_STEMW))[i] = ((const f32x4*)a.stem_w)[i];
+    int* toks = (int*)(smem + G_OFF_TOKS);
+    if (tid < 16 * 2 * NT + 8) {
+      const int p = p0 - 4 + tid;
+      toks[tid] = ((unsigned)p < (unsigned)L) ? (int)a.x_tok[(long)b * L + p] : -1;
+    }
+    __syncthreads();
+  }
   {   // the residual stream: this lane's 8 channels of its positions
     const int lo = opaque(lane);
     const int pn = (lo & 15) ^ ((lo & 8) >> 1);
     const int ch0 = 32 * ct + 4 * (lo >> 4);
-    const float* f0 = a.feat_in + (long)b * L * 128 + ch0;
+    if (a.x_tok) {
+      // k_stem_tok's sum (drk_cnn_f32.hip): one weight row per tap picked by the token, taps in order, then the bias
+      const float* wl = (const float*)(smem + G_OFF_STEMW) + ch0;
+      const int* toks = (const int*)(smem + G_OFF_TOKS);
+      f32x4 sb[2];
+      load_vec8(a.stem_b, ch0, sb);
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const int p = p0 + a.stride * (16 * (grp + 2 * t) + pn);
-      const bool ok = (unsigned)p < (unsigned)L;
-      vmask |= ok ? (1u << t) : 0u;
-      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      feat[t][0] = ok ? *(const f32x4*)(f0 + (long)p * 128) : z;
-      feat[t][1] = ok ? *(const f32x4*)(f0 + (long)p * 128 + 16) : z;
+      for (int t = 0; t < NT; ++t) {
+        const int k = 16 * (grp + 2 * t) + pn;
+        const bool ok = (unsigned)(p0 + k) < (unsigned)L;
+        vmask |= ok ? (1u << t) : 0u;
+        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          const int tk = toks[k + tap];
+          if ((unsigned)tk < 5u) {
+            s0 += *(const f32x4*)(wl + (tap * 5 + tk) * 128);
+            s1 += *(const f32x4*)(wl + (tap * 5 + tk) * 128 + 16);
+          }
+        }
+        s0 += sb[0];
+        s1 += sb[1];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          feat[t][0][i] = ok ? fmaxf(s0[i], 0.f) : 0.f;
+          feat[t][1][i] = ok ? fmaxf(s1[i], 0.f) : 0.f;
+        }
+      }
+    } else {
+      const float* f0 = a.feat_in + (long)b * L * 128 + ch0;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int p = p0 + a.stride * (16 * (grp + 2 * t) + pn);
+        const bool ok = (unsigned)p < (unsigned)L;
+        vmask |= ok ? (1u << t) : 0u;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        feat[t][0] = ok ? *(const f32x4*)(f0 + (long)p * 128) : z;
+        feat[t][1] = ok ? *(const f32x4*)(f0 + (long)p * 128 + 16) : z;
+      }
     }
   }
   __syncthreads();   // image zeroed, tables resident
@@ -203,18 +251,98 @@ __device__ __forceinline__ void group_body(const GroupArgs& a, char* smem, int t
         *(f32x4*)(fo + (long)p * 128 + 16) = feat[t][1];
       }
     }
-    if (a.h_out) {   // bf16 of the stream through the image: whole 256-byte rows leave
+    if (a.h_out || a.logits) {   // bf16 of the stream into the image
       __syncthreads();   // the last layer did no LayerNorm: every wave is past its reads of the image
 #pragma unroll
       for (int t = 0; t < NT; ++t)
         if ((vmask >> t) & 1u) store_h8(smem, 16 * (grp + 2 * t) + pn, ch0, feat[t]);
       __syncthreads();
+    }
+    if (a.h_out) {   // whole 256-byte rows leave
       char* ho = a.h_out + (long)b * L * 256;
       for (int i = tid; i < a.T * 16; i += 512) {
         const int k = a.halo + (i >> 4);
         const int p = p0 + a.stride * k;
         if ((unsigned)p < (unsigned)L)
           *(f32x4*)(ho + (long)p * 256 + 16 * (i & 15)) = *(const f32x4*)(smem + OFF_HB + k * ROWB + 16 * (i & 15));
+      }
+    }
+  }
+  if (!a.logits) return;
+
+  // ---- the head: final_conv.0 (1x1, its fragments are in the ring: the tap behind the last layer's ninth) + ReLU, then
+  // final_conv.2 (128 -> 5) in fp32 with k_head_out's arithmetic on the y tile staged through LDS, 128 rows at a time
+  {
+#pragma clang fp contract(off)
+    {
+      f32x4 cbl[2];
+      load_vec8(vecs + 384 * a.n + 128, 32 * ct + 4 * (opaque(lane) >> 4), cbl);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        acc[t][0] = cbl[0];
+        acc[t][1] = cbl[1];
+      }
+      const char* hcur = pad_base(smem, lane);
+      bf16v8 cur[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) cur[t] = *(const bf16v8*)(hcur + RI(GRP, t, 0));
+      mma_tap_pad<NT, GRP, false>(hcur, hcur, wuni + (long)(9 * a.n) * TAP_BYTES, loff, ring, cur, acc);   // (the refill is unused)
+    }
+    const int lo = opaque(lane);
+    const int pn = (lo & 15) ^ ((lo & 8) >> 1);
+    const int ch0 = 32 * ct + 4 * (lo >> 4);
+    float* const stg = (float*)(smem + OFF_HB - HPAD * ROWB);      // [128][132] floats = 67 584 B of the image area
+    float* const ws = (float*)(smem + G_OFF_PART);                 // [5][128]
+    float* lg = a.logits + (long)b * L * DRK_V;
+    const int s8 = tid & 7;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      __syncthreads();   // every wave is past its reads of the image (half 0) / of the staged rows (half 1)
+      if (half == 0)
+        for (int i = tid; i < DRK_V * DRK_C; i += 512) ws[i] = a.head_w[i];
+#pragma unroll
+      for (int t = 4 * half; t < (half ? NT : 4); ++t) {
+        const int rl = 16 * (grp + 2 * t) + pn - 128 * half;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          f32x4 yv;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) yv[i] = fmaxf(acc[t][s][i], 0.f);
+          *(f32x4*)(stg + rl * G_STG_STRIDE + ch0 + 16 * s) = yv;
+        }
+      }
+      __syncthreads();
+#pragma unroll 1
+      for (int pass = 0; pass < 2; ++pass) {
+        const int rowl = 64 * pass + (tid >> 3);
+        const int k = 128 * half + rowl;
+        const int p = p0 + a.stride * k;
+        const bool ok = k < 32 * NT && (unsigned)p < (unsigned)L && (unsigned)(k - a.halo) < (unsigned)a.T;
+        float part[DRK_V] = {0.f, 0.f, 0.f, 0.f, 0.f};
+        if (ok) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const int ch = 4 * (s8 + 8 * c);
+            const f32x4 av = *(const f32x4*)(stg + rowl * G_STG_STRIDE + ch);
+#pragma unroll
+            for (int v = 0; v < DRK_V; ++v) {
+              const f32x4 ww = *(const f32x4*)(ws + v * DRK_C + ch);
+              part[v] += (av[0] * ww[0] + av[1] * ww[1]) + (av[2] * ww[2] + av[3] * ww[3]);
+            }
+          }
+        }
+#pragma unroll
+        for (int v = 0; v < DRK_V; ++v) {
+          part[v] += __shfl_xor(part[v], 4);
+          part[v] += __shfl_xor(part[v], 2);
+          part[v] += __shfl_xor(part[v], 1);
+        }
+        if (ok && s8 < DRK_V) {
+          float o = part[0];
+#pragma unroll
+          for (int v = 1; v < DRK_V; ++v) o = (s8 == v) ? part[v] : o;
+          lg[(long)p * DRK_V + s8] = o + a.head_b[s8];
+        }
       }
     }
   }
@@ -244,15 +372,24 @@ extern "C" long drk_layer_group_bf16_rows(int n_group, int tiles16) {
 //               feat_out may be feat_in.
 //   stride = 1: every dilation in 1..4 (halo = 4 x their sum), tiles16 = 14 or 16 (image rows / 16), feat_out != feat_in.
 // wstream / vecs / tbias: the WHOLE model's fragment stream, vector table and time-bias table [n_layers][128] (one time
-// for the batch), as drk_sample_bf16 takes them; dilations: the group's n_group TRUE dilations.  h_out: also leaves
-// bf16 of the outgoing stream as rows (the operand of drk_head_bf16), or NULL; feat_out may be NULL when h_out is given.
-extern "C" int drk_layer_group_bf16(const float* feat_in, float* feat_out, void* h_out, const void* wstream, const float* vecs,
-                                    const float* tbias, int B, int L, int first_layer, int n_group, int stride, int tiles16,
-                                    const int* dilations, void* stream) {
+// for the batch), as drk_sample_bf16 takes them; dilations: the group's n_group TRUE dilations.
+// In: feat_in, or (first_layer = 0, stride = 1) the tokens x_tok with the stem's stem_w_t [9][5][128] / stem_b [128]: the
+// stem runs in the launch.  Out, any of: feat_out (fp32 stream); h_out (its bf16 rows, drk_head_bf16's operand); logits
+// [B*L][5] with head_w [5][128] / head_b [5]: the head runs in the launch (the caller says so only for the group that
+// ends the stack: the tap behind the group's last layer is then final_conv.0).
+extern "C" int drk_layer_group_bf16(const float* feat_in, const int64_t* x_tok, const float* stem_w_t, const float* stem_b,
+                                    float* feat_out, void* h_out, float* logits, const float* head_w, const float* head_b,
+                                    const void* wstream, const float* vecs, const float* tbias, int B, int L, int first_layer,
+                                    int n_group, int stride, int tiles16, const int* dilations, void* stream) {
   DRK_SHAPE_GUARD("drk_layer_group_bf16");
-  if (!feat_in || (!feat_out && !h_out) || !wstream || !vecs || !tbias || !dilations)
-    return drk_set_error_msg(DRK_EINVAL, "drk_layer_group_bf16: null pointer");
-  if (((uintptr_t)feat_in | (uintptr_t)feat_out | (uintptr_t)h_out | (uintptr_t)wstream | (uintptr_t)vecs | (uintptr_t)tbias) & 15)
+  if ((!feat_in == !x_tok) || (!feat_out && !h_out && !logits) || !wstream || !vecs || !tbias || !dilations)
+    return drk_set_error_msg(DRK_EINVAL, "drk_layer_group_bf16: null pointer (one of feat_in / x_tok, at least one output)");
+  if (x_tok && (!stem_w_t || !stem_b || first_layer != 0 || stride != 1))
+    return drk_set_error_msg(DRK_EINVAL, "drk_layer_group_bf16: tokens come with stem_w_t, stem_b, first_layer = 0, stride = 1");
+  if (logits && (!head_w || !head_b))
+    return drk_set_error_msg(DRK_EINVAL, "drk_layer_group_bf16: logits come with head_w, head_b");
+  if (((uintptr_t)feat_in | (uintptr_t)feat_out | (uintptr_t)h_out | (uintptr_t)wstream | (uintptr_t)vecs | (uintptr_t)tbias |
+       (uintptr_t)stem_w_t | (uintptr_t)stem_b | (uintptr_t)head_w) & 15)
     return drk_set_error_msg(DRK_EINVAL, "drk_layer_group_bf16: 16-byte aligned pointers");
   if (first_layer < 0 || n_group < 1 || n_group > G_MAX_LAYERS || stride < 1 || (tiles16 != 14 && tiles16 != 16))
     return drk_set_error_msg(DRK_EINVAL, "drk_layer_group_bf16: 1..12 layers, stride >= 1, tiles16 = 14 or 16");
@@ -277,7 +414,7 @@ extern "C" int drk_layer_group_bf16(const float* feat_in, float* feat_out, void*
   } else {
     a.halo = reach; a.T = 16 * tiles16 - 2 * reach;
     if (a.T < 16) return drk_set_error_msg(DRK_EINVAL, "drk_layer_group_bf16: the group's halo leaves no rows to write");
-    if (feat_in == feat_out) return drk_set_error_msg(DRK_EINVAL, "drk_layer_group_bf16: stride 1 reads its neighbours' rows: feat_out != feat_in");
+    if (feat_in && feat_in == feat_out) return drk_set_error_msg(DRK_EINVAL, "drk_layer_group_bf16: stride 1 reads its neighbours' rows: feat_out != feat_in");
     a.tiles_per_seq = (L + a.T - 1) / a.T;
   }
   const long grid = (long)B * a.tiles_per_seq;
@@ -286,6 +423,7 @@ extern "C" int drk_layer_group_bf16(const float* feat_in, float* feat_out, void*
   a.vecs = vecs + (long)first_layer * 384;
   a.tbias = tbias + (long)first_layer * 128;
   a.feat_in = feat_in; a.feat_out = feat_out; a.h_out = (char*)h_out;
+  a.x_tok = x_tok; a.stem_w = stem_w_t; a.stem_b = stem_b; a.logits = logits; a.head_w = head_w; a.head_b = head_b;
   a.B = B; a.L = L; a.n = n_group; a.stride = stride;
   const int which = has16 ? 2 : (tiles16 == 16 ? 1 : 0);
   const void* kern = which == 2 ? (const void*)k_group_bf16<8, true> : which == 1 ? (const void*)k_group_bf16<8, false>

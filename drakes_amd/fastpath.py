@@ -231,6 +231,12 @@ def hard_steps_bf16(model, batch, table, n_hard, seed, sample_offset, uniforms):
 
 
 # ---- layer-per-launch bf16 path (any length) ------------------------------------------------------------------------
+def _i64_ptr(t):
+    if not t.is_cuda or t.dtype != torch.int64 or not t.is_contiguous():
+        raise TypeError('expected a contiguous int64 tensor on the GPU')
+    return ctypes.c_void_p(t.data_ptr())
+
+
 def _bf16_ptr(t, name):
     if t is None:
         return None
@@ -285,6 +291,7 @@ def forward_bf16_layers(bb, seq, tbias, tb_stride, work=None):
 GROUP_HALO_LAYERS = 4      # dilation-1 layers per launch in halo mode (4 recomputed rows per layer and side)
 GROUP_HALO_TILES = 16      # image rows / 16 in halo mode: 256 rows, 224 of them written with four layers (5 images per
                            # 1024 rows, as with two layers in 224-row images; half the launches and bytes)
+GROUP_FUSE_ENDS = True     # the stem runs in the first launch (token input), the head in the last; False: their own launches
 GROUP_MIN_FILL = 0.6       # the dispatcher below takes the groups when a stride-mode image is at least this full
 
 
@@ -317,11 +324,48 @@ def group_plan(bb, L, halo_layers=None, halo_tiles=None):
     return plan
 
 
+def group_launches(bb, seq, tbias, work, plan, keep_feat=False):
+    """The argument tuples of the grouped forward's drk_layer_group_bf16 calls, in order: [(plan entry, args)], and whether
+    the head still needs its own launch.  Buffers come from `work`."""
+    pk, st = bb.packed(), _packed(bb)
+    B, L = seq.shape[0], seq.shape[1]
+    n = bb.num_layers
+    def buf(name, dtype, *shape):
+        t = work.get(name)
+        if t is None or t.shape != torch.Size(shape) or t.dtype != dtype:
+            t = torch.empty(*shape, dtype=dtype, device=seq.device)
+            work[name] = t
+        return t
+    fp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    feat = [buf('feat', torch.float32, B, L, ops.C), buf('feat1', torch.float32, B, L, ops.C)]
+    logits = buf('logits', torch.float32, B, L, ops.V)
+    tokens = seq.dtype == torch.int64 and plan[0][0] == 0 and plan[0][2] == 1 and GROUP_FUSE_ENDS   # stem in the first launch
+    tb = tbias[0].contiguous()
+    cur, out, head = 0, [], False
+    for gi, (l0, ng, stride, tiles16) in enumerate(plan):
+        last = gi + 1 == len(plan)
+        first = gi == 0 and tokens
+        head = last and l0 + ng == n and GROUP_FUSE_ENDS and not keep_feat          # the head runs in the last launch
+        dst = cur if (stride > 1 and not first) else cur ^ 1                        # stride mode works in place
+        dil = (ctypes.c_int * ng)(*[bb.dilation(l0 + k) for k in range(ng)])
+        fout = fp(feat[dst]) if (keep_feat or not last) else None
+        hout = _bf16_ptr(buf('h0', torch.bfloat16, B, L, ops.C), 'h') if (last and not head) else None
+        out.append(((l0, ng, stride, tiles16),
+                    (None if first else fp(feat[cur]), _i64_ptr(seq) if first else None, fp(pk['stem_w']) if first else None,
+                     fp(pk['stem_b']) if first else None, fout, hout, fp(logits) if head else None,
+                     fp(pk['head2_w']) if head else None, fp(pk['head2_b']) if head else None, fp(st['wstream']), fp(st['vecs']),
+                     fp(tb), B, L, l0, ng, stride, tiles16, dil, ops._stream())))
+        cur = dst
+    work['feat_final'] = feat[cur] if keep_feat else None
+    return out, tokens, head
+
+
 def forward_bf16_groups(bb, seq, tbias, work=None, plan=None, keep_feat=False):
     """Raw logits [B,L,5] as forward_bf16_layers gives them (same rounding points), with the residual layers run several
     per launch (drk_layer_group_bf16, csrc/drk_group_bf16.hip): only the fp32 residual stream passes through HBM between
-    launches.  tbias [1, n_layers, 128]: one time for the batch.  keep_feat: the last group also writes its fp32 stream
-    (work['feat_final']; tests), which nothing else reads."""
+    launches; with token input the stem runs inside the first launch, the head inside the last (GROUP_FUSE_ENDS).
+    tbias [1, n_layers, 128]: one time for the batch.  keep_feat: the last group also writes its fp32 stream
+    (work['feat_final']; tests), which nothing else reads; the head then takes its own launch."""
     pk, st = bb.packed(), _packed(bb)
     B, L = seq.shape[0], seq.shape[1]
     n = bb.num_layers
@@ -333,32 +377,16 @@ def forward_bf16_groups(bb, seq, tbias, work=None, plan=None, keep_feat=False):
         raise NotImplementedError('drk_layer_group_bf16 takes one time for the batch: use forward_bf16_layers')
     if work is None:
         work = {}
-    def buf(name, dtype, *shape):
-        t = work.get(name)
-        if t is None or t.shape != torch.Size(shape) or t.dtype != dtype:
-            t = torch.empty(*shape, dtype=dtype, device=seq.device)
-            work[name] = t
-        return t
-    fp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
-    feat = [buf('feat', torch.float32, B, L, ops.C), buf('feat1', torch.float32, B, L, ops.C)]
-    h = buf('h0', torch.bfloat16, B, L, ops.C)
-    ops.stem_fwd(seq, pk['stem_w'], pk['stem_b'], out=feat[0])
-    tb = tbias[0].contiguous()
-    cur = 0
-    for gi, (l0, ng, stride, tiles16) in enumerate(plan):
-        last = gi + 1 == len(plan)
-        dst = cur if stride > 1 else cur ^ 1                      # stride mode works in place
-        dil = (ctypes.c_int * ng)(*[bb.dilation(l0 + k) for k in range(ng)])
-        fout = fp(feat[dst]) if (keep_feat or not last) else None
-        args = (fp(feat[cur]), fout, _bf16_ptr(h, 'h') if last else None, fp(st['wstream']), fp(st['vecs']), fp(tb), B, L,
-                l0, ng, stride, tiles16, dil, ops._stream())
+    launches, tokens, head = group_launches(bb, seq, tbias, work, plan, keep_feat)
+    if not tokens:
+        ops.stem_fwd(seq, pk['stem_w'], pk['stem_b'], out=work['feat'])
+    for (l0, ng, stride, tiles16), args in launches:
         ops.PROFILE.bracket('k_group_bf16', 2.0 * B * L * 9 * ops.C * ops.C * ng, lambda: _lib.call('drk_layer_group_bf16', *args))
-        cur = dst
-    work['feat_final'] = feat[cur] if keep_feat else None
-    logits = buf('logits', torch.float32, B, L, ops.V)
-    _lib.call('drk_head_bf16', _bf16_ptr(h, 'h'), fp(st['wstream'][9 * n:]), fp(st['vecs'][3 * n + 1]), fp(pk['head2_w']),
-              fp(pk['head2_b']), fp(logits), B, L, ops._stream())
-    return logits
+    if not head:
+        fp = lambda t: ctypes.c_void_p(t.data_ptr())
+        _lib.call('drk_head_bf16', _bf16_ptr(work['h0'], 'h'), fp(st['wstream'][9 * n:]), fp(st['vecs'][3 * n + 1]), fp(pk['head2_w']),
+                  fp(pk['head2_b']), fp(work['logits']), B, L, ops._stream())
+    return work['logits']
 
 
 def forward_bf16_long(bb, seq, tbias, tb_stride, work=None):

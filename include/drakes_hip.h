@@ -300,12 +300,17 @@ int drk_head_bf16(const void* h, const void* wfrag, const float* bias, const flo
  *   stride = 1: consecutive rows with a recomputed halo of 4 * (sum of the dilations) rows either side; dilations in
  *               1..4; tiles16 = 14 or 16 (image rows / 16); feat_out != feat_in.
  * wstream, vecs, tbias: the whole model's fragment stream, vector table and time biases [n_layers][128] (one row for
- * the batch) as drk_sample_bf16 takes them; dilations: the group's n_group true dilations.  h_out: NULL, or bf16
- * [B*L][128] = bf16 of the outgoing stream, the operand of drk_head_bf16; with h_out given feat_out may be NULL (the
- * stack's last group: nothing reads its fp32 stream). */
-int drk_layer_group_bf16(const float* feat_in, float* feat_out, void* h_out, const void* wstream, const float* vecs,
-                         const float* tbias, int B, int L, int first_layer, int n_group, int stride, int tiles16,
-                         const int* dilations, void* stream);
+ * the batch) as drk_sample_bf16 takes them; dilations: the group's n_group true dilations.
+ * In: feat_in, or (first_layer = 0, stride = 1 only) the tokens x_tok int64 [B*L] with the stem's w_t [9][5][128] and bias
+ * as drk_stem_fwd takes them: the stem (dnaconv.py:80-86) then runs in the launch, with drk_stem_fwd's bits.
+ * Out, any of: feat_out; h_out bf16 [B*L][128] = bf16 of the outgoing stream (the operand of drk_head_bf16); logits
+ * float32 [B*L][5] with head_w [5][128], head_b [5]: the head (dnaconv.py:60-63, 103-104) runs in the launch with
+ * drk_head_bf16's arithmetic — only for the group that ends the stack (the tap behind its last layer in wstream is
+ * final_conv.0). */
+int drk_layer_group_bf16(const float* feat_in, const int64_t* x_tok, const float* stem_w_t, const float* stem_b,
+                         float* feat_out, void* h_out, float* logits, const float* head_w, const float* head_b,
+                         const void* wstream, const float* vecs, const float* tbias, int B, int L, int first_layer,
+                         int n_group, int stride, int tiles16, const int* dilations, void* stream);
 /* Rows of feat_out one workgroup of drk_layer_group_bf16 writes at stride = 1 (0: the group does not fit the image). */
 long drk_layer_group_bf16_rows(int n_group, int tiles16);
 

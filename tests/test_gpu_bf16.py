@@ -331,6 +331,25 @@ def test_group_plans_agree_bitwise(gpu_model, dev):
     assert torch.equal(fastpath.forward_bf16_groups(bb, x, tbias, None, split), base)
 
 
+def test_group_fused_ends_equal_their_own_launches_bitwise(gpu_model, dev, monkeypatch):
+    """The stem inside the first launch (token input) and the head inside the last one carry the arithmetic of
+    drk_stem_fwd and drk_head_bf16: same logits, bit for bit, as with those two as launches of their own; soft (float)
+    input takes the stem launch either way."""
+    bb = gpu_model.backbone
+    tbias = bb.time_bias(torch.full((1,), 0.4, device=dev))
+    for B, L in [(2, 1024), (3, 997), (1, 240)]:
+        gen = np.random.Generator(np.random.PCG64(5 + L))
+        x = torch.from_numpy(gen.integers(0, 5, (B, L))).to(dev)
+        for plan in [None, fastpath.group_plan(bb, L, 2, 14)]:
+            fused = fastpath.forward_bf16_groups(bb, x, tbias, None, plan).clone()
+            monkeypatch.setattr(fastpath, 'GROUP_FUSE_ENDS', False)
+            apart = fastpath.forward_bf16_groups(bb, x, tbias, None, plan).clone()
+            monkeypatch.setattr(fastpath, 'GROUP_FUSE_ENDS', True)
+            assert torch.equal(fused, apart), (B, L, plan)
+        soft = torch.nn.functional.one_hot(x, 5).float()
+        assert torch.equal(fastpath.forward_bf16_groups(bb, soft, tbias), fused)
+
+
 def test_group_entry_point_rejects_what_it_cannot_run(gpu_model, dev):
     bb = gpu_model.backbone
     x = torch.zeros(1, 2048, dtype=torch.int64, device=dev)

@@ -43,19 +43,10 @@ def main():
     for name, plan in plans.items():
         w2 = {}
         out[f'groups_{name}_us'] = timed(lambda: fastpath.forward_bf16_groups(bb, x, tbias, w2, plan))
-        # launch by launch
+        # launch by launch (the first with the stem, the last with the head)
+        launches, _, _ = fastpath.group_launches(bb, x, tbias, w2, plan)
         per = []
-        for g in plan:
-            # just this group on whatever the buffers hold (timing only: the values do not matter)
-            pk, st = bb.packed(), fastpath._packed(bb)
-            import ctypes
-            fp = lambda t: ctypes.c_void_p(t.data_ptr())
-            fa, fb = w2['feat'], w2['feat1']
-            l0, ng, stride, tiles16 = g
-            dil = (ctypes.c_int * ng)(*[bb.dilation(l0 + k) for k in range(ng)])
-            tb = tbias[0].contiguous()
-            args = (fp(fa), fp(fa if stride > 1 else fb), None, fp(st['wstream']), fp(st['vecs']), fp(tb), B, L, l0, ng, stride,
-                    tiles16, dil, ops._stream())
+        for g, args in launches:
             per.append((g, round(timed(lambda: drakes_amd._lib.call('drk_layer_group_bf16', *args)), 1)))
         out[f'groups_{name}_launches'] = per
     print(json.dumps(out))
