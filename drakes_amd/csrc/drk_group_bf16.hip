@@ -17,19 +17,20 @@
 //
 // Work split, lane <-> data maps, tap loops: drk_sample_bf16.hip / drk_fused_common.h (8 waves = 4 channel tiles x 2
 // position groups; wave (ct, grp) owns row tiles grp, grp + 2, ... and channels 32 ct .. 32 ct + 31).
-#define ZROW 271                 // image rows 0..255, then 16 all-zero rows (HPAD more in front)
+#define ZROW 303                 // image rows 0..287 (stride mode: 0..255), then all-zero rows (HPAD more in front)
 #define DRK_LIVE_END 256
 #include "drk_fused_common.h"
 
-#define G_ROWS 256
+#define G_ROWS 288               // halo mode: up to 18 tiles of 16 rows
+#define G_STRIDE_ROWS 256        // stride mode: 16 tiles, rows 256.. are padding (DRK_LIVE_END)
 #define G_MAX_LAYERS 12
-#define G_IMG_BYTES ((HPAD + ZROW + 1) * ROWB)                    // 78 336
-#define G_OFF_PART G_IMG_BYTES                                    // float [256][12]: LayerNorm partials
+#define G_IMG_BYTES ((HPAD + ZROW + 1) * ROWB)                    // 87 040
+#define G_OFF_PART G_IMG_BYTES                                    // float [288][12]: LayerNorm partials
 #define G_OFF_VECS (G_OFF_PART + G_ROWS * PART_STRIDE * 4)        // float [n+1][3][128]: blocks first_layer .. first_layer + n
 #define G_OFF_TB (G_OFF_VECS + (G_MAX_LAYERS + 1) * 3 * 128 * 4)  // float [n][128]
 #define G_OFF_STEMW (G_OFF_TB + G_MAX_LAYERS * 128 * 4)           // float [9][5][128]: the stem's weights (token input only)
-#define G_OFF_TOKS (G_OFF_STEMW + 9 * 5 * 128 * 4)                // int [256 + 8]: tokens of image rows -4 .. 259
-#define G_LDS_BYTES (G_OFF_TOKS + (G_ROWS + 8) * 4)               // 140 832
+#define G_OFF_TOKS (G_OFF_STEMW + 9 * 5 * 128 * 4)                // int [288 + 8]: tokens of image rows -4 .. 291
+#define G_LDS_BYTES (G_OFF_TOKS + (G_ROWS + 8) * 4)               // 151 200
 #define G_STG_STRIDE 132                                          // floats per row of the head's fp32 staging tile [128][132]
 
 struct GroupArgs {
@@ -143,7 +144,7 @@ __device__ __forceinline__ void group_body(const GroupArgs& a, char* smem, int t
   if (a.x_tok) {   // (uniform) tokens in: the stem's weights and this image's tokens go to LDS first
     for (int i = tid; i < 9 * 5 * 128 / 4; i += 512) ((f32x4*)(smem + G_OFF_STEMW))[i] = ((const f32x4*)a.stem_w)[i];
     int* toks = (int*)(smem + G_OFF_TOKS);
-    if (tid < 16 * 2 * NT + 8) {
+    if (tid < 32 * NT + 8) {
       const int p = p0 - 4 + tid;
       toks[tid] = ((unsigned)p < (unsigned)L) ? (int)a.x_tok[(long)b * L + p] : -1;
     }
@@ -296,12 +297,12 @@ __device__ __forceinline__ void group_body(const GroupArgs& a, char* smem, int t
     float* lg = a.logits + (long)b * L * DRK_V;
     const int s8 = tid & 7;
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      __syncthreads();   // every wave is past its reads of the image (half 0) / of the staged rows (half 1)
+    for (int half = 0; half < (2 * NT + 7) / 8; ++half) {   // 128 image rows = the wave's tiles 4 half .. 4 half + 3
+      __syncthreads();   // every wave is past its reads of the image (half 0) / of the staged rows
       if (half == 0)
         for (int i = tid; i < DRK_V * DRK_C; i += 512) ws[i] = a.head_w[i];
 #pragma unroll
-      for (int t = 4 * half; t < (half ? NT : 4); ++t) {
+      for (int t = 4 * half; t < (4 * half + 4 < NT ? 4 * half + 4 : NT); ++t) {
         const int rl = 16 * (grp + 2 * t) + pn - 128 * half;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -362,7 +363,7 @@ __global__ void __launch_bounds__(512, 2) k_group_bf16(const GroupArgs a) {
 // Rows of feat_out one workgroup writes in halo mode (stride 1), 0 when the group does not fit an image of `tiles16`
 // 16-row tiles; workgroups per sequence = ceil(L / that).
 extern "C" long drk_layer_group_bf16_rows(int n_group, int tiles16) {
-  if (n_group < 1 || n_group > G_MAX_LAYERS || (tiles16 != 14 && tiles16 != 16)) return 0;
+  if (n_group < 1 || n_group > G_MAX_LAYERS || (tiles16 != 14 && tiles16 != 16 && tiles16 != 18)) return 0;
   const long T = 16L * tiles16 - 8L * n_group;
   return T >= 16 ? T : 0;
 }
@@ -370,7 +371,7 @@ extern "C" long drk_layer_group_bf16_rows(int n_group, int tiles16) {
 // Layers first_layer .. first_layer + n_group - 1 of the residual stack in one launch (see the head of this file).
 //   stride > 1: every dilation a multiple of `stride`, dilation / stride in {1..4, 16}, ceil(L / stride) <= 256; tiles16 = 16;
 //               feat_out may be feat_in.
-//   stride = 1: every dilation in 1..4 (halo = 4 x their sum), tiles16 = 14 or 16 (image rows / 16), feat_out != feat_in.
+//   stride = 1: every dilation in 1..4 (halo = 4 x their sum), tiles16 = 14, 16 or 18 (image rows / 16), feat_out != feat_in.
 // wstream / vecs / tbias: the WHOLE model's fragment stream, vector table and time-bias table [n_layers][128] (one time
 // for the batch), as drk_sample_bf16 takes them; dilations: the group's n_group TRUE dilations.
 // In: feat_in, or (first_layer = 0, stride = 1) the tokens x_tok with the stem's stem_w_t [9][5][128] / stem_b [128]: the
@@ -391,8 +392,9 @@ extern "C" int drk_layer_group_bf16(const float* feat_in, const int64_t* x_tok, 
   if (((uintptr_t)feat_in | (uintptr_t)feat_out | (uintptr_t)h_out | (uintptr_t)wstream | (uintptr_t)vecs | (uintptr_t)tbias |
        (uintptr_t)stem_w_t | (uintptr_t)stem_b | (uintptr_t)head_w) & 15)
     return drk_set_error_msg(DRK_EINVAL, "drk_layer_group_bf16: 16-byte aligned pointers");
-  if (first_layer < 0 || n_group < 1 || n_group > G_MAX_LAYERS || stride < 1 || (tiles16 != 14 && tiles16 != 16))
-    return drk_set_error_msg(DRK_EINVAL, "drk_layer_group_bf16: 1..12 layers, stride >= 1, tiles16 = 14 or 16");
+  if (first_layer < 0 || n_group < 1 || n_group > G_MAX_LAYERS || stride < 1 ||
+      (tiles16 != 14 && tiles16 != 16 && tiles16 != 18))
+    return drk_set_error_msg(DRK_EINVAL, "drk_layer_group_bf16: 1..12 layers, stride >= 1, tiles16 = 14, 16 or 18");
   GroupArgs a;
   a.dilpk[0] = a.dilpk[1] = 0;
   bool has16 = false;
@@ -408,9 +410,9 @@ extern "C" int drk_layer_group_bf16(const float* feat_in, const int64_t* x_tok, 
     a.dilpk[i >> 3] |= (unsigned long long)di << (8 * (i & 7));
   }
   if (stride > 1) {
-    if (tiles16 != 16 || ((long)L + stride - 1) / stride > G_ROWS)
+    if (tiles16 != 16 || ((long)L + stride - 1) / stride > G_STRIDE_ROWS)
       return drk_set_error_msg(DRK_EINVAL, "drk_layer_group_bf16: stride > 1 takes tiles16 = 16 and ceil(L / stride) <= 256");
-    a.halo = 0; a.T = G_ROWS; a.tiles_per_seq = stride;
+    a.halo = 0; a.T = G_STRIDE_ROWS; a.tiles_per_seq = stride;
   } else {
     a.halo = reach; a.T = 16 * tiles16 - 2 * reach;
     if (a.T < 16) return drk_set_error_msg(DRK_EINVAL, "drk_layer_group_bf16: the group's halo leaves no rows to write");
@@ -425,10 +427,10 @@ extern "C" int drk_layer_group_bf16(const float* feat_in, const int64_t* x_tok, 
   a.feat_in = feat_in; a.feat_out = feat_out; a.h_out = (char*)h_out;
   a.x_tok = x_tok; a.stem_w = stem_w_t; a.stem_b = stem_b; a.logits = logits; a.head_w = head_w; a.head_b = head_b;
   a.B = B; a.L = L; a.n = n_group; a.stride = stride;
-  const int which = has16 ? 2 : (tiles16 == 16 ? 1 : 0);
-  const void* kern = which == 2 ? (const void*)k_group_bf16<8, true> : which == 1 ? (const void*)k_group_bf16<8, false>
-                                                                                  : (const void*)k_group_bf16<7, false>;
-  static std::atomic<unsigned> lds_set[3][DRK_MAX_DEVICES];
+  const int which = has16 ? 2 : (tiles16 == 18 ? 3 : tiles16 == 16 ? 1 : 0);
+  const void* kern = which == 2 ? (const void*)k_group_bf16<8, true> : which == 3 ? (const void*)k_group_bf16<9, false>
+                   : which == 1 ? (const void*)k_group_bf16<8, false> : (const void*)k_group_bf16<7, false>;
+  static std::atomic<unsigned> lds_set[4][DRK_MAX_DEVICES];
   {
     int devid = 0;
     hipError_t e = hipGetDevice(&devid);
@@ -441,6 +443,8 @@ extern "C" int drk_layer_group_bf16(const float* feat_in, const int64_t* x_tok, 
   }
   if (which == 2)
     hipLaunchKernelGGL((k_group_bf16<8, true>), dim3((unsigned)grid), dim3(512), G_LDS_BYTES, (hipStream_t)stream, a);
+  else if (which == 3)
+    hipLaunchKernelGGL((k_group_bf16<9, false>), dim3((unsigned)grid), dim3(512), G_LDS_BYTES, (hipStream_t)stream, a);
   else if (which == 1)
     hipLaunchKernelGGL((k_group_bf16<8, false>), dim3((unsigned)grid), dim3(512), G_LDS_BYTES, (hipStream_t)stream, a);
   else

@@ -288,11 +288,26 @@ def forward_bf16_layers(bb, seq, tbias, tb_stride, work=None):
 
 
 # ---- several layers per launch (drk_layer_group_bf16): long sequences ---------------------------------------------------
-GROUP_HALO_LAYERS = 4      # dilation-1 layers per launch in halo mode (4 recomputed rows per layer and side)
-GROUP_HALO_TILES = 16      # image rows / 16 in halo mode: 256 rows, 224 of them written with four layers (5 images per
-                           # 1024 rows, as with two layers in 224-row images; half the launches and bytes)
+GROUP_HALO_LAYERS = None   # dilation-1 layers per launch in halo mode (4 recomputed rows per layer and side) and
+GROUP_HALO_TILES = None    # image rows / 16 there (14, 16 or 18); None: whatever _halo_shape finds cheapest for the length
 GROUP_FUSE_ENDS = True     # the stem runs in the first launch (token input), the head in the last; False: their own launches
 GROUP_MIN_FILL = 0.6       # the dispatcher below takes the groups when a stride-mode image is at least this full
+
+
+def _halo_shape(L, run):
+    """(layers per launch, image tiles) for a run of `run` dilation-1 layers at length L: the pair with the fewest
+    16-row tile passes per layer, a launch's fixed cost (stream in and out, first LayerNorm: about 12 tile passes per
+    workgroup) spread over its layers.  L = 1024: (4, 18) - 256 of 288 image rows written, 4 workgroups a sequence."""
+    best = None
+    for hl in (4, 3, 2, 1):
+        if hl > run:
+            continue
+        for ht in (18, 16, 14):
+            T = 16 * ht - 8 * hl
+            cost = -(-L // T) * (ht + 12.0 / hl)
+            if best is None or cost < best[0]:
+                best = (cost, hl, ht)
+    return best[1], best[2]
 
 
 def group_plan(bb, L, halo_layers=None, halo_tiles=None):
@@ -300,9 +315,14 @@ def group_plan(bb, L, halo_layers=None, halo_tiles=None):
     (first_layer, n, stride, tiles16), or None when some layer fits neither mode.  Runs of dilation-1 layers go `halo_layers`
     at a time with a recomputed halo; a layer of dilation d > 1 opens a stride-d group that takes every following layer
     whose dilation is d x {1..4, 16} (the rows of one residue class mod d are closed under all of their shifts)."""
-    hl = halo_layers or GROUP_HALO_LAYERS
-    ht = halo_tiles or GROUP_HALO_TILES
     dil = [bb.dilation(i) for i in range(bb.num_layers)]
+    run = 0
+    while run < len(dil) and dil[run] == 1:
+        run += 1
+    hl, ht = halo_layers or GROUP_HALO_LAYERS, halo_tiles or GROUP_HALO_TILES
+    if hl is None or ht is None:
+        auto = _halo_shape(L, max(run, 1))
+        hl, ht = hl or auto[0], ht or auto[1]
     plan, i, n = [], 0, len(dil)
     while i < n:
         d = dil[i]

@@ -298,7 +298,7 @@ int drk_head_bf16(const void* h, const void* wfrag, const float* bias, const flo
  *               multiple of stride, dilation / stride in {1..4, 16}, ceil(L / stride) <= 256, tiles16 = 16; feat_out
  *               may be feat_in.
  *   stride = 1: consecutive rows with a recomputed halo of 4 * (sum of the dilations) rows either side; dilations in
- *               1..4; tiles16 = 14 or 16 (image rows / 16); feat_out != feat_in.
+ *               1..4; tiles16 = 14, 16 or 18 (image rows / 16); feat_out != feat_in.
  * wstream, vecs, tbias: the whole model's fragment stream, vector table and time biases [n_layers][128] (one row for
  * the batch) as drk_sample_bf16 takes them; dilations: the group's n_group true dilations.
  * In: feat_in, or (first_layer = 0, stride = 1 only) the tokens x_tok int64 [B*L] with the stem's w_t [9][5][128] and bias

@@ -261,7 +261,10 @@ def test_group_path_logits(gpu_model, dev, det_sd, B, L):
         ref = O.cnn_forward(det_sd, x, torch.zeros(B)).numpy()
     bb = gpu_model.backbone
     tbias = bb.time_bias(torch.zeros(1, device=dev))
-    assert fastpath.group_plan(bb, L) == [(0, 4, 1, 16), (4, 4, 1, 16), (8, 12, 4, 16)]
+    plan = fastpath.group_plan(bb, L)
+    assert plan[-1] == (8, 12, 4, 16) and all(g[2] == 1 for g in plan[:-1]) and sum(g[1] for g in plan) == 20
+    if L == 1024:
+        assert plan == [(0, 4, 1, 18), (4, 4, 1, 18), (8, 12, 4, 16)]
     got = fastpath.forward_bf16_groups(bb, x.to(dev), tbias).cpu().numpy()
     lay = fastpath.forward_bf16_layers(bb, x.to(dev), tbias, 0).cpu().numpy()
     print(f'L={L}: max|groups-emulation|={np.abs(got - emu).max():.2e}  max|groups-fp32|={np.abs(got - ref).max():.2e}  '
@@ -320,7 +323,7 @@ def test_group_plans_agree_bitwise(gpu_model, dev):
     x = torch.from_numpy(gen.integers(0, 5, (B, L))).to(dev)
     tbias = bb.time_bias(torch.full((1,), 0.7, device=dev))
     base = fastpath.forward_bf16_groups(bb, x, tbias).clone()
-    for hl, ht in [(1, 14), (2, 14), (2, 16), (8, 16), (3, 14)]:
+    for hl, ht in [(1, 14), (2, 14), (2, 16), (4, 16), (8, 16), (3, 14), (4, 18), (1, 18), (12, 18)]:
         plan = fastpath.group_plan(bb, L, hl, ht)
         assert torch.equal(fastpath.forward_bf16_groups(bb, x, tbias, None, plan), base), (hl, ht)
     split = [(0, 2, 1, 14), (2, 2, 1, 14), (4, 2, 1, 14), (6, 2, 1, 14), (8, 4, 4, 16), (12, 5, 4, 16), (17, 3, 4, 16)]
@@ -340,7 +343,7 @@ def test_group_fused_ends_equal_their_own_launches_bitwise(gpu_model, dev, monke
     for B, L in [(2, 1024), (3, 997), (1, 240)]:
         gen = np.random.Generator(np.random.PCG64(5 + L))
         x = torch.from_numpy(gen.integers(0, 5, (B, L))).to(dev)
-        for plan in [None, fastpath.group_plan(bb, L, 2, 14)]:
+        for plan in [None, fastpath.group_plan(bb, L, 2, 14), fastpath.group_plan(bb, L, 3, 18), [(0, 12, 1, 18), (12, 8, 16, 16)]]:
             fused = fastpath.forward_bf16_groups(bb, x, tbias, None, plan).clone()
             monkeypatch.setattr(fastpath, 'GROUP_FUSE_ENDS', False)
             apart = fastpath.forward_bf16_groups(bb, x, tbias, None, plan).clone()
@@ -348,6 +351,31 @@ def test_group_fused_ends_equal_their_own_launches_bitwise(gpu_model, dev, monke
             assert torch.equal(fused, apart), (B, L, plan)
         soft = torch.nn.functional.one_hot(x, 5).float()
         assert torch.equal(fastpath.forward_bf16_groups(bb, soft, tbias), fused)
+
+
+@pytest.mark.parametrize('tiles16', [14, 16, 18])
+def test_group_head_in_every_image_size_bitwise(gpu_model, dev, tiles16):
+    """The in-launch head on the 224-, 256- and 288-row halo images (the standard stack ends in stride mode, so only the
+    256-row image meets it there): layers 4..7 with the tap behind them standing in for final_conv.0, against the same
+    group leaving bf16 rows + drk_head_bf16 on that tap.  Tokens in, so the in-launch stem is not what is compared."""
+    import ctypes
+    bb = gpu_model.backbone
+    pk, st = bb.packed(), fastpath._packed(bb)
+    B, L = 2, 700
+    feat = torch.randn(B, L, 128, device=dev)
+    tb = bb.time_bias(torch.full((1,), 0.9, device=dev))[0].contiguous()
+    P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    dil = (ctypes.c_int * 4)(1, 1, 1, 1)
+    h = torch.zeros(B, L, 128, dtype=torch.bfloat16, device=dev)
+    lg1 = torch.zeros(B, L, 5, device=dev)
+    lg2 = torch.zeros(B, L, 5, device=dev)
+    common = (P(st['wstream']), P(st['vecs']), P(tb), B, L, 4, 4, 1, tiles16, dil, ops._stream())
+    _lib.call('drk_layer_group_bf16', P(feat), None, None, None, None, P(h), None, None, None, *common)
+    _lib.call('drk_head_bf16', P(h), P(st['wstream'][9 * 8:]), P(st['vecs'][3 * 8 + 1]), P(pk['head2_w']), P(pk['head2_b']), P(lg1),
+              B, L, ops._stream())
+    _lib.call('drk_layer_group_bf16', P(feat), None, None, None, None, None, P(lg2), P(pk['head2_w']), P(pk['head2_b']), *common)
+    assert lg1.abs().max().item() > 0.1
+    assert torch.equal(lg1, lg2)
 
 
 def test_group_entry_point_rejects_what_it_cannot_run(gpu_model, dev):
