@@ -26,8 +26,9 @@ def timed(fn, reps=10):
 
 
 def main():
-    B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-    L = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+    pos = [a for a in sys.argv[1:] if not a.startswith('--')]
+    B = int(pos[0]) if len(pos) > 0 else 256
+    L = int(pos[1]) if len(pos) > 1 else 1024
     dev = torch.device('cuda:0')
     m = drakes_amd.Diffusion(drakes_amd.default_config(length=L)).to(dev)
     m.load_state_dict(det_state_dict(0))
@@ -36,10 +37,18 @@ def main():
     x[:, ::3] = 4
     tbias = bb.time_bias(torch.zeros(1, device=dev))
     out = {'B': B, 'L': L, 'drk_version': drakes_amd._lib.load().drk_version()}
+    if '--pmc' in sys.argv:                      # under rocprofv3 --pmc: three forwards of the shipped plan, nothing else
+        w0 = {}
+        for _ in range(3):
+            fastpath.forward_bf16_groups(bb, x, tbias, w0)
+        torch.cuda.synchronize()
+        return
     work = {}
     out['layers_us'] = timed(lambda: fastpath.forward_bf16_layers(bb, x, tbias, 0, work))
-    plans = {'h2x14': fastpath.group_plan(bb, L, 2, 14), 'h4x16': fastpath.group_plan(bb, L, 4, 16),
-             'h1x14': fastpath.group_plan(bb, L, 1, 14), 'h8x16': fastpath.group_plan(bb, L, 8, 16)}
+    plans = {'auto': fastpath.group_plan(bb, L), 'h4x16': fastpath.group_plan(bb, L, 4, 16),
+             'split444': [(0, 4, 1, 18), (4, 4, 1, 18), (8, 4, 4, 16), (12, 4, 4, 16), (16, 4, 4, 16)],
+             'split84': [(0, 4, 1, 18), (4, 4, 1, 18), (8, 8, 4, 16), (16, 4, 4, 16)],
+             'h2x18': fastpath.group_plan(bb, L, 2, 18)}
     for name, plan in plans.items():
         w2 = {}
         out[f'groups_{name}_us'] = timed(lambda: fastpath.forward_bf16_groups(bb, x, tbias, w2, plan))
