@@ -207,3 +207,62 @@ def test_native_denoiser_entry_points_reject_bad_arguments():
     assert lib.drk_denoiser_masks_bytes(4, 200, 20, ops.denoiser_flags(True)) == 20 * 4 * 200 * 128
     assert lib.drk_denoiser_bwd_bf16_slab_floats(20) == 21 * 512 + lib.drk_head_bwd_bf16_slab_floats()
     assert lib.drk_denoiser_bwd_bf16_slabs(128, 200) == 256 + 16 + 1 and lib.drk_denoiser_bwd_bf16_slabs(2, 4096) == 64 + 4 + 1
+
+
+def test_group_plan_covers_the_stack_once():
+    """fastpath.group_plan (host logic of the grouped long-sequence forward): every layer in exactly one group, halo groups
+    only over dilations 1..4, stride groups closed under their stride, nothing planned where an image would overflow."""
+    from drakes_amd import fastpath
+
+    class Stack:
+        def __init__(self, dil):
+            self.dil, self.num_layers = dil, len(dil)
+
+        def dilation(self, i):
+            return self.dil[i]
+
+    std = Stack([1] * 8 + [4] * 4 + [16] * 4 + [64] * 4)
+    assert fastpath.group_plan(std, 1024) == [(0, 4, 1, 18), (4, 4, 1, 18), (8, 12, 4, 16)]
+    assert fastpath.group_plan(std, 2048) is None and fastpath.group_plan(std, 1025) is None
+    lib = _lib.load()
+    for L in (225, 300, 640, 777, 1000, 1024):
+        for hl, ht in [(None, None), (1, 14), (2, 16), (8, 18), (12, 16)]:
+            plan = fastpath.group_plan(std, L, hl, ht)
+            assert [l for g in plan for l in range(g[0], g[0] + g[1])] == list(range(20)), (L, plan)
+            for l0, n, s, t16 in plan:
+                d = std.dil[l0:l0 + n]
+                if s == 1:
+                    assert all(1 <= x <= 4 for x in d) and lib.drk_layer_group_bf16_rows(n, t16) == 16 * t16 - 8 * sum(d) >= 16
+                else:
+                    assert t16 == 16 and n <= 12 and all(x % s == 0 and x // s in (1, 2, 3, 4, 16) for x in d) and -(-L // s) <= 256
+    cyc = Stack([1, 1, 4, 16, 64] * 2)                      # a stack that cycles its dilations: groups stay short
+    assert fastpath.group_plan(cyc, 1024) == [(0, 2, 1, 18), (2, 3, 4, 16), (5, 2, 1, 18), (7, 3, 4, 16)]
+    odd = Stack([1, 5, 25])
+    assert fastpath.group_plan(odd, 1024) == [(0, 1, 1, 18), (1, 1, 5, 16), (2, 1, 25, 16)]
+    assert lib.drk_layer_group_bf16_rows(4, 18) == 256 and lib.drk_layer_group_bf16_rows(2, 14) == 208
+    assert lib.drk_layer_group_bf16_rows(13, 16) == 0 and lib.drk_layer_group_bf16_rows(2, 15) == 0
+
+
+def test_group_entry_point_argument_errors():
+    """drk_layer_group_bf16 rejects bad arguments before anything is launched (runs without a GPU)."""
+    P = 0x10000
+    d1 = (ctypes.c_int * 4)(1, 1, 1, 1)
+    d4 = (ctypes.c_int * 4)(4, 4, 16, 64)
+
+    def call(feat_in=P, x_tok=None, stem_w=None, stem_b=None, feat_out=P + 0x100000, h_out=None, logits=None, head_w=None,
+             head_b=None, B=2, L=1024, first=0, n=4, stride=1, t16=16, dil=d1):
+        return _lib.call('drk_layer_group_bf16', feat_in, x_tok, stem_w, stem_b, feat_out, h_out, logits, head_w, head_b, P, P, P,
+                         B, L, first, n, stride, t16, ctypes.cast(dil, ctypes.c_void_p), None)
+
+    for kw, needle in [(dict(feat_in=None), 'one of feat_in / x_tok'), (dict(x_tok=P), 'one of feat_in / x_tok'),
+                       (dict(feat_out=None), 'at least one output'), (dict(feat_in=None, x_tok=P), 'tokens come with'),
+                       (dict(feat_in=None, x_tok=P, stem_w=P, stem_b=P, first=4), 'tokens come with'),
+                       (dict(feat_in=None, x_tok=P, stem_w=P, stem_b=P, stride=4, dil=d4), 'tokens come with'),
+                       (dict(logits=P), 'logits come with'), (dict(feat_in=P + 4), 'aligned'), (dict(n=0), '1..12 layers'),
+                       (dict(n=13), '1..12 layers'), (dict(t16=15), 'tiles16'), (dict(stride=0), 'stride >= 1'),
+                       (dict(stride=4, dil=d1), 'multiple of stride'), (dict(dil=d4), 'dilation / stride'),
+                       (dict(stride=4, dil=d4, t16=18), 'tiles16 = 16'), (dict(stride=4, dil=d4, L=1025), '<= 256'),
+                       (dict(feat_out=P), 'feat_out != feat_in'), (dict(L=0), 'bad shape'), (dict(B=-1), 'bad shape')]:
+        with pytest.raises(_lib.DrakesHipError, match=re.escape(needle)):
+            call(**kw)
+    call(B=0)                                             # an empty batch is a no-op
