@@ -394,7 +394,7 @@ def test_group_entry_point_rejects_what_it_cannot_run(gpu_model, dev):
 
 def test_long_sequences_take_the_layer_path(dev, det_sd):
     """L = 1024 (BASELINE.json configs[4]) with hip_dtype = 'bf16': beyond the fused kernel's 224 positions, _sample runs
-    the layer-per-launch kernels with the fp32 path's step kernels.  Tokens: valid, shard-invariant, same number
+    the per-forward bf16 launches (since round 3 the grouped ones, drk_layer_group_bf16) with the fp32 path's step kernels.  Tokens: valid, shard-invariant, same number
     unmasked as the fp32 path (the unmasking decision does not depend on logits), few flips."""
     m = drakes_amd.Diffusion(drakes_amd.default_config(length=1024, steps=6)).to(dev)
     m.load_state_dict(det_sd)
