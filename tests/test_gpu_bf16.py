@@ -378,6 +378,36 @@ def test_group_head_in_every_image_size_bitwise(gpu_model, dev, tiles16):
     assert torch.equal(lg1, lg2)
 
 
+def test_long_sampling_dispatch_and_time_conditioning(dev, det_sd, monkeypatch):
+    """_sample at L = 1024 with a new time every step (time_conditioning: a fresh [1, n, 128] bias table per forward,
+    no captured step): the grouped launches against the layer-per-launch path the dispatcher takes when told that no
+    image is full enough, and against the fp32 kernels; get_likelihood goes through the same dispatcher."""
+    m = drakes_amd.Diffusion(drakes_amd.default_config(length=1024, steps=5, time_conditioning=True)).to(dev)
+    m.load_state_dict(det_sd)
+    calls = []
+    real = fastpath.forward_bf16_groups
+    monkeypatch.setattr(fastpath, 'forward_bf16_groups', lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    f32 = m._sample(eval_sp_size=2, seed=4).cpu()
+    m.hip_dtype = 'bf16'
+    grouped = m._sample(eval_sp_size=2, seed=4).cpu()
+    assert len(calls) == 6                                        # 5 steps + noise removal
+    monkeypatch.setattr(fastpath, 'GROUP_MIN_FILL', 2.0)
+    m.backbone._group_plans = {}
+    layered = m._sample(eval_sp_size=2, seed=4).cpu()
+    assert len(calls) == 6
+    print('L=1024 time-conditioned: groups vs layers', (grouped != layered).float().mean().item(), ' groups vs fp32',
+          (grouped != f32).float().mean().item())
+    assert (grouped != layered).float().mean().item() <= 0.03 and (grouped != f32).float().mean().item() <= 0.03
+    monkeypatch.setattr(fastpath, 'GROUP_MIN_FILL', 0.6)
+    m.backbone._group_plans = {}
+    x0 = grouped.to(dev)
+    ll_g = m.get_likelihood(x0, num_steps=3, seed=9).cpu()
+    assert len(calls) == 9
+    m.hip_dtype = 'fp32'
+    ll_f = m.get_likelihood(x0, num_steps=3, seed=9).cpu()
+    np.testing.assert_allclose(ll_g.numpy(), ll_f.numpy(), rtol=2e-2)
+
+
 def test_group_entry_point_rejects_what_it_cannot_run(gpu_model, dev):
     bb = gpu_model.backbone
     x = torch.zeros(1, 2048, dtype=torch.int64, device=dev)
