@@ -587,7 +587,6 @@ __device__ __forceinline__ void train_bwd_body(const TrainBwdArgs& a, char* smem
     const int m = m_next;
     m_next = layer ? reach_of(layer - 1) : 0;
     const long after = layer ? 9 * (layer - 1) + 4 - m_next : 9 * layer + 4 - m;      // (layer 0: the refill is unused)
-    const long rows = (long)layer * M + b * L;
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t][0] = acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
     const char* wn = (FAST ? wuni : wlane) + (long)(9 * layer + 4 - m + 1) * TAP_BYTES;
