@@ -265,6 +265,7 @@ def secondary_fp32(model, B=1024, dtype='fp32'):
 # The dominant launch of configs[4] (k_group_bf16<8,true>: layers 8..19 + head, B=256, L=1024): tools/pmc_group.sh,
 # profiles/r3_group_v310_pmc.json.  Printed only while drk_version() is the version it was taken on.
 PMC_TRAFFIC_LONG = {'drk_version': 310, 'bytes_per_launch': 385431424.0, 'fetch_bytes': 303639296.0, 'write_bytes': 81792128.0,
+                    'launch': 'the largest of the three: layers 8..19 + head, stride 4 (the two halo launches: 360 MB each)',
                     'algorithmic_bytes': 256 * 1024 * (512 + 20.0),
                     'note': 'L2-to-fabric requests (FETCH_SIZE doubled per MI355X_MICROARCH.md); beyond the 134 MB of residual '
                             'stream: the 3.5 MB weight stream of the 12 layers re-fetched from the Infinity Cache and 49 '
@@ -298,9 +299,11 @@ def _time_layer_kernel(model, B, Ll, reps=20):
 
 
 def _time_group_kernels(model, B, Ll, reps=10):
-    """Every launch of the grouped long-sequence forward (drk_layer_group_bf16; the first with the stem, the last with the
-    head) timed alone after the run, same shapes, HIP events on its stream.  Returns [(plan entry, ms, dense FLOP)], or
-    None when the shape takes the layer path."""
+    """The launches of the grouped long-sequence forward (drk_layer_group_bf16; the first with the stem, the last with the
+    head) timed after the run, same shapes, HIP events on their stream: (a) `reps` forwards captured into one hipGraph
+    and replayed, as the timed region runs them -> ms per forward; (b) every launch on its own, back to back (they run
+    5-10 % slower that way than inside the captured sequence).  Returns (ms per forward, [(plan entry, ms alone, dense
+    FLOP)]), or None when the shape takes the layer path."""
     from drakes_amd import _lib, fastpath
     bb = model.backbone
     plan = fastpath.group_plan(bb, Ll)
@@ -312,18 +315,35 @@ def _time_group_kernels(model, B, Ll, reps=10):
     tbias = bb.time_bias(torch.zeros(1, device=dev))
     fastpath.forward_bf16_groups(bb, x, tbias, work, plan)            # fills the buffers with a real forward's values
     launches, _, _ = fastpath.group_launches(bb, x, tbias, work, plan)
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        captured, _, _ = fastpath.group_launches(bb, x, tbias, work, plan)     # (the argument tuples carry the stream)
+        for _ in range(reps):
+            for _, a in captured:
+                _lib.call('drk_layer_group_bf16', *a)
+    torch.cuda.current_stream().wait_stream(side)
+    graph.replay()
+    s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s_.record()
+    for _ in range(3):
+        graph.replay()
+    e_.record()
+    torch.cuda.synchronize()
+    fwd_ms = s_.elapsed_time(e_) / (3 * reps)
     out = []
     for entry, a in launches:
         for _ in range(2):
             _lib.call('drk_layer_group_bf16', *a)
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
-        for s_, e_ in evs:
-            s_.record()
+        s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s_.record()
+        for _ in range(reps):
             _lib.call('drk_layer_group_bf16', *a)
-            e_.record()
+        e_.record()
         torch.cuda.synchronize()
-        out.append((entry, sum(s_.elapsed_time(e_) for s_, e_ in evs) / reps, 2.0 * B * Ll * 9 * 128 * 128 * entry[1]))
-    return out
+        out.append((entry, s_.elapsed_time(e_) / reps, 2.0 * B * Ll * 9 * 128 * 128 * entry[1]))
+    return fwd_ms, out
 
 
 def workload_long(args, rank, world, dev, barrier):
@@ -349,17 +369,19 @@ def workload_long(args, rank, world, dev, barrier):
     roof = {'bound': 'mfma', 'kernel': name, 'launches_timed': n, 'avg_launch_ms': ms}
     groups = _time_group_kernels(m, B, Ll) if (not n and args.dtype == 'bf16') else None
     if groups:
-        # the captured step replays without passing the launch brackets: every launch of the forward timed on its own
-        # after the timed region.  Dominant: the stride-mode launch (the twelve dilation-4/16/64 layers), MFMA-bound:
-        # one launch moves 1 KB per row through HBM for 12 x 295 kFLOP per row
-        g, gms, gfl = max(groups, key=lambda t: t[1])
-        roof = {'bound': 'mfma', 'kernel': f'k_group_bf16 (layers {g[0]}..{g[0] + g[1] - 1}, stride {g[2]}, timed alone after the run)',
-                'launches_timed': 10, 'avg_launch_ms': gms, 'achieved': gfl / gms / 1e9, 'peak': 2500.0, 'unit': 'TFLOP/s',
-                'traffic': None, 'flop_per_row_and_layer': 2 * 9 * 128 * 128,
-                'hbm_GBps': rows * 1024 / (gms * 1e-3) / 1e9,
-                'forward_launches_ms': [[list(e), round(t, 4)] for e, t, _ in groups],
-                'forward_layers_ms_total': sum(t for _, t, _ in groups),
-                'forward_TFLOPs_dense': sum(f for _, _, f in groups) / sum(t for _, t, _ in groups) / 1e9}
+        # the captured step replays without passing the launch brackets.  Dominant kernel: k_group_bf16, whose three
+        # launches are the forward (two halo launches of four dilation-1 layers, one stride-4 launch of the twelve
+        # dilation-4/16/64 layers and the head); MFMA-bound: a forward moves 2.1 KB per row through HBM for 20 x 295 kFLOP
+        fwd_ms, per = groups
+        flop = sum(f for _, _, f in per)
+        g, gms, gfl = max(per, key=lambda t: t[1])
+        roof = {'bound': 'mfma', 'kernel': f'k_group_bf16 (the {len(per)} launches of one forward, replayed from a hipGraph after the run)',
+                'launches_timed': 30 * len(per), 'avg_launch_ms': fwd_ms / len(per), 'forward_ms': fwd_ms,
+                'achieved': flop / fwd_ms / 1e9, 'peak': 2500.0, 'unit': 'TFLOP/s',
+                'traffic': None, 'flop_per_row_and_layer': 2 * 9 * 128 * 128, 'flop_per_forward': flop,
+                'hbm_GBps': rows * 2068 / (fwd_ms * 1e-3) / 1e9,
+                'launches_alone_ms': [[list(e), round(t, 4)] for e, t, _ in per],
+                'largest_launch_alone': {'plan': list(g), 'ms': gms, 'TFLOPs_dense': gfl / gms / 1e9}}
         roof['frac'] = roof['achieved'] / roof['peak']
         from drakes_amd import _lib
         if B == 256 and PMC_TRAFFIC_LONG['drk_version'] == _lib.load().drk_version():
