@@ -18,6 +18,9 @@ Same arguments and return value as the reference function.  Differences, all add
     running two forwards and a backward each; losses and gradients are bit-identical either way (tested on F6 a);
   * `reuse_sampling_forward` (default on): see kl_of_step — the KL term of a soft step reuses the logits the sampler
     computed from the same tensor instead of a second forward/backward of the new model;
+  * `kl_streams` (default 2; 0 = off): the frozen model's forwards of the KL term run round-robin on that many side
+    streams, and autograd runs their input-gradient launches there too, beside the new model's backward chain (at
+    fine-tune batch sizes one launch fills at most half of the chip); same values;
   * under torch.distributed (drakes_amd.dp) every rank runs its own shard (`args.batch_size` rows per rank); the flat
     gradient bucket is all-reduced once, after the last accumulation micro-step and BEFORE clipping (:89-92).
 The reward models are the caller's torch modules (the gReLU model in the reference, oracle.py:230-262): outside the
@@ -32,7 +35,7 @@ import torch.nn.functional as F
 from . import autograd, dp
 
 
-def kl_of_step(new_model, old_model, last_x, condt, move_chance_t, copy_flag, reuse_sampling_forward=True):
+def kl_of_step(new_model, old_model, last_x, condt, move_chance_t, copy_flag, reuse_sampling_forward=True, old_logp=None):
     """kl_div [B] of one recorded reverse step — finetune_reward_bp.py:63-74, one fused kernel each way.
 
     On soft steps last_x carries the sampling graph, so the reference's gradient also runs back through
@@ -49,7 +52,9 @@ def kl_of_step(new_model, old_model, last_x, condt, move_chance_t, copy_flag, re
         log_p_x0 = new_model._subs_parameterization(logits=hit[1], xt=last_x)
     else:
         log_p_x0 = new_model.forward(last_x, condt)
-    if last_x.requires_grad:
+    if old_logp is not None:
+        log_p_x0_old = old_logp
+    elif last_x.requires_grad:
         log_p_x0_old = old_model.forward(last_x, condt)
     else:
         with torch.no_grad():
@@ -57,9 +62,43 @@ def kl_of_step(new_model, old_model, last_x, condt, move_chance_t, copy_flag, re
     return autograd.kl_step_with_grad(log_p_x0, log_p_x0_old, last_x, copy_flag, float(move_chance_t.reshape(-1)[0]))
 
 
+def old_model_forwards(old_model, steps, last_x_list, condt_list, n_streams):
+    """{step: old_model.forward(last_x[step], condt[step])} for the given steps, run round-robin on `n_streams` side
+    streams: the forwards are independent of each other, and at fine-tune batch sizes (one workgroup per sequence, 32-128
+    sequences) each fills at most half of the chip.  autograd runs each one's backward on the stream of its forward, so
+    the frozen model's input-gradient launches overlap the new model's backward chain the same way.  The caller's
+    stream waits for the side streams before this returns."""
+    cur = torch.cuda.current_stream()
+    streams = _side_streams(cur.device, n_streams)
+    out = {}
+    for s in streams:
+        s.wait_stream(cur)
+    for k, t in enumerate(steps):
+        with torch.cuda.stream(streams[k % n_streams]):
+            if last_x_list[t].requires_grad:
+                out[t] = old_model.forward(last_x_list[t], condt_list[t])
+            else:
+                with torch.no_grad():
+                    out[t] = old_model.forward(last_x_list[t], condt_list[t])
+            out[t].record_stream(cur)
+    for s in streams:
+        cur.wait_stream(s)
+    return out
+
+
+_STREAMS = {}
+
+
+def _side_streams(device, n):
+    key = (device.index, n)
+    if key not in _STREAMS:
+        _STREAMS[key] = [torch.cuda.Stream(device=device) for _ in range(n)]
+    return _STREAMS[key]
+
+
 def fine_tune(new_model, new_model_y, new_model_y_eval, old_model, args, eps=1e-5, *, log_path=None, save_path=None,
               seed_of_call=None, verbose=True, on_update=None, skip_hard_step_kl=True,
-              reuse_sampling_forward=True):
+              reuse_sampling_forward=True, kl_streams=2):
     if log_path is not None:
         with open(log_path, 'w') as f:
             f.write(args.__repr__() + '\n')
@@ -102,14 +141,19 @@ def fine_tune(new_model, new_model_y, new_model_y_eval, old_model, args, eps=1e-
                 rewards_eval.append(new_model_y_eval(sample_argmax).squeeze(-1)[:, 0].cpu().numpy())
 
             total_kl = []
-            for random_t in range(args.total_num_steps):                                      # :60-75
-                if args.truncate_kl and random_t < args.total_num_steps - args.truncate_steps:
-                    continue
+            kl_steps = [t for t in range(args.total_num_steps)                                # :60-75
+                        if not (args.truncate_kl and t < args.total_num_steps - args.truncate_steps)]
+            run_steps = [t for t in kl_steps if not (skip_hard_step_kl and copy_flag_list[t].dtype == torch.int64)]
+            old_logps = {}
+            if kl_streams and sample.is_cuda and len(run_steps) > 1:
+                old_logps = old_model_forwards(old_model, run_steps, last_x_list, condt_list, kl_streams)
+            for random_t in kl_steps:
                 if skip_hard_step_kl and copy_flag_list[random_t].dtype == torch.int64:
                     total_kl.append(torch.zeros(args.batch_size, dtype=torch.float32, device=sample.device))
                     continue
                 total_kl.append(kl_of_step(new_model, old_model, last_x_list[random_t], condt_list[random_t],
-                                           move_chance_t_list[random_t], copy_flag_list[random_t], reuse_sampling_forward))
+                                           move_chance_t_list[random_t], copy_flag_list[random_t], reuse_sampling_forward,
+                                           old_logps.get(random_t)))
 
             if epoch_num < args.alpha_schedule_warmup:                                        # :77-81, linear warm-up
                 current_alpha = (epoch_num + 1) / args.alpha_schedule_warmup * args.alpha
