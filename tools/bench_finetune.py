@@ -30,18 +30,19 @@ def loop(a):
     for p in reward.parameters():
         p.requires_grad_(False)
     args = NS(truncate_steps=a.trunc, gumbel_temp=1.0, total_num_steps=a.steps, learning_rate=1e-4, num_epochs=1,
-              num_accum_steps=1, batch_size=a.batch, copy_flag_temp=None, truncate_kl=False, alpha=0.001,
+              num_accum_steps=a.accum, batch_size=a.batch, copy_flag_temp=None, truncate_kl=False, alpha=0.001,
               alpha_schedule_warmup=0, gradnorm_clip=1.0, save_every_n_epochs=10 ** 9)
     ts = []
     for r in range(a.reps + 1):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        drakes_amd.fine_tune(new_model, reward, reward, old_model, args, verbose=False, **({'kl_streams': a.kl_streams} if a.kl_streams is not None else {}))
+        drakes_amd.fine_tune(new_model, reward, reward, old_model, args, verbose=False, **({'kl_streams': a.kl_streams} if a.kl_streams is not None else {}),
+                             **({'micro_streams': a.micro_streams} if a.micro_streams is not None else {}))
         torch.cuda.synchronize()
         ts.append(time.perf_counter() - t0)
         print(f'rep {r}: {ts[-1]:.3f} s per optimizer step', flush=True)
     res = {'workload': f'fine_tune optimizer step: _sample_finetune_gradient (K={a.trunc}) + reward + KL over all {a.steps} '
-                       f'steps (new + frozen model) + backward + clip + Adam, batch {a.batch}, L={a.length}, {a.dtype} kernels',
+                       f'steps (new + frozen model) + backward + clip + Adam, batch {a.batch} x {a.accum} micro-steps, L={a.length}, {a.dtype} kernels',
            'seconds_per_step': sorted(ts[1:])[len(ts[1:]) // 2], 'peak_mem_GiB': torch.cuda.max_memory_allocated() / 2 ** 30}
     print(json.dumps(res), flush=True)
     if a.json:
@@ -59,6 +60,8 @@ def main():
     ap.add_argument('--json', default=None)
     ap.add_argument('--dtype', default='fp32', choices=['fp32', 'bf16x3', 'bf16'], help="hip_dtype: 'bf16' = fused hard phase + bf16 soft steps and backward; 'bf16x3' = fp32-grade convolutions on bf16 MFMA")
     ap.add_argument('--loop', action='store_true', help='time whole fine_tune optimizer steps (sampling + reward + KL over all steps + Adam)')
+    ap.add_argument('--accum', type=int, default=1, help='--loop: micro-steps per optimizer step (the reference default is 4)')
+    ap.add_argument('--micro-streams', type=int, default=None, help='fine_tune(micro_streams=...): lanes of an accumulation window (1: none)')
     ap.add_argument('--kl-streams', type=int, default=None, help='fine_tune(kl_streams=...): side streams of the frozen model (0: none)')
     a = ap.parse_args()
     if a.loop:
