@@ -36,17 +36,19 @@ def _frag_stem(w):
     return wk.permute(3, 0, 1, 4, 2, 5).contiguous().reshape(3, 4, 2, 64, 8)
 
 
+def _frag_taps(m):
+    """_frag_tap for a batch of matrices [T][128 co][128 ci] in one pass (the packing runs after every optimizer step)."""
+    w = m.to(torch.bfloat16).reshape(-1, 4, 2, 16, 2, 2, 4, 8)     # [T][ct][s][n][g&1][g>>1][ks][j]
+    return w.permute(0, 6, 1, 2, 5, 4, 3, 7).contiguous().reshape(-1, 4, 4, 2, 64, 8)
+
+
 def pack_stream(bb):
     """bb: models.dnaconv.CNNModel -> dict of device tensors the fused kernel reads."""
     dev = bb.linear.weight.device
     n = bb.num_layers
     with torch.no_grad():
-        stages = []
-        for i in range(n):
-            w = bb.convs[i].weight          # [co][ci][tap]
-            for t in range(9):
-                stages.append(_frag_tap(w[:, :, t]))
-        stages.append(_frag_tap(bb.final_conv[0].weight[:, :, 0]))
+        w = torch.stack([bb.convs[i].weight for i in range(n)])                 # [n][co][ci][tap]
+        mats = torch.cat([w.permute(0, 3, 1, 2).reshape(9 * n, 128, 128), bb.final_conv[0].weight[:, :, 0][None]])
         head2 = torch.zeros(128, 128, device=dev)
         head2[:ops.V] = bb.final_conv[2].weight[:, :, 0]
         # epilogue blocks of 3 vectors: block 0 = stem bias, gamma_0, beta_0; block k+1 = conv bias_k,
@@ -60,7 +62,7 @@ def pack_stream(bb):
             else:
                 vec_rows += [bb.convs[k].bias, bb.final_conv[0].bias, hb2]
         return {
-            'wstream': torch.stack(stages).contiguous(),
+            'wstream': _frag_taps(mats),
             'stem_w': _frag_stem(bb.linear.weight.detach()),
             'head2_w': head2[:8].to(torch.bfloat16).contiguous(),
             'vecs': torch.stack([v.detach().float() for v in vec_rows]).contiguous(),
@@ -74,13 +76,10 @@ def pack_stream_T(bb):
     (dh[r][ci] = sum_t sum_co dc[r + (t-4)d][co] * w[co][ci][8-t]), then final_conv.0 transposed."""
     n = bb.num_layers
     with torch.no_grad():
-        stages = []
-        for i in range(n):
-            wt = bb.convs[i].weight.transpose(0, 1).flip(2)          # [ci][co][tap]
-            for t in range(9):
-                stages.append(_frag_tap(wt[:, :, t]))
-        stages.append(_frag_tap(bb.final_conv[0].weight[:, :, 0].t()))
-        return torch.stack(stages).contiguous()
+        w = torch.stack([bb.convs[i].weight for i in range(n)])                 # [n][co][ci][tap]
+        wt = w.permute(0, 3, 2, 1).flip(1)                                      # [n][8 - tap][ci][co]
+        mats = torch.cat([wt.reshape(9 * n, 128, 128), bb.final_conv[0].weight[:, :, 0].t()[None]])
+        return _frag_taps(mats)
 
 
 def _packed_T(bb):

@@ -35,6 +35,20 @@ class Dense(nn.Module):
         self.dense = nn.Linear(input_dim, output_dim)
 
 
+class _LazyPack(dict):
+    """packed() entries plus some that are computed when first read (under no_grad: they are copies of the weights)."""
+
+    def __init__(self, base, makers):
+        super().__init__(base)
+        self._makers = makers
+
+    def __missing__(self, key):
+        with torch.no_grad():
+            value = self._makers[key]()
+        self[key] = value
+        return value
+
+
 class CNNModel(nn.Module):
     def __init__(self, args, alphabet_size, num_cls, classifier=False):
         super().__init__()
@@ -142,7 +156,16 @@ class CNNModel(nn.Module):
             with torch.no_grad():
                 n = self.num_layers
                 P = {k: self.wide(k, v.detach()) for k, v in self.named_parameters()}
-                self._packed = {
+                # the exact-fp32 convolutions' layouts are built on first use: the bf16 paths, which come through here for
+                # the stem / time / head weights after every optimizer step, never read them
+                lazy = {
+                    'conv_w': lambda: [ops.pack_conv_weight_f32(P[f'convs.{i}.weight']) for i in range(n)],
+                    # input-gradient weights: the same kernel run on weight.transpose(0,1).flip(2)
+                    'conv_wT': lambda: [ops.pack_conv_weight_f32(P[f'convs.{i}.weight'].transpose(0, 1).flip(2)) for i in range(n)],
+                    'head0_wT': lambda: ops.pack_conv_weight_f32(P['final_conv.0.weight'].transpose(0, 1)),
+                    'head0_w': lambda: ops.pack_conv_weight_f32(P['final_conv.0.weight']),
+                }
+                self._packed = _LazyPack({
                     'stem_w': ops.pack_stem_weight(P['linear.weight']),
                     'stem_b': P['linear.bias'].contiguous(),
                     'four_W': P['time_embedder.0.W'].contiguous(),
@@ -152,16 +175,11 @@ class CNNModel(nn.Module):
                     'dense_b': torch.stack([P[f'time_layers.{i}.dense.bias'] for i in range(n)]).contiguous(),
                     'ln_g': [P[f'norms.{i}.weight'].contiguous() for i in range(n)],
                     'ln_b': [P[f'norms.{i}.bias'].contiguous() for i in range(n)],
-                    'conv_w': [ops.pack_conv_weight_f32(P[f'convs.{i}.weight']) for i in range(n)],
-                    # input-gradient weights: the same kernel run on weight.transpose(0,1).flip(2)
-                    'conv_wT': [ops.pack_conv_weight_f32(P[f'convs.{i}.weight'].transpose(0, 1).flip(2)) for i in range(n)],
-                    'head0_wT': ops.pack_conv_weight_f32(P['final_conv.0.weight'].transpose(0, 1)),
                     'conv_b': [P[f'convs.{i}.bias'].contiguous() for i in range(n)],
-                    'head0_w': ops.pack_conv_weight_f32(P['final_conv.0.weight']),
                     'head0_b': P['final_conv.0.bias'].contiguous(),
                     'head2_w': P['final_conv.2.weight'].reshape(self.alphabet_size, -1).contiguous(),
                     'head2_b': P['final_conv.2.bias'].contiguous(),
-                }
+                }, lazy)
             self._packed_key = key
         return self._packed
 
