@@ -61,6 +61,7 @@ SIGNATURES = {
     'drk_layer_bwd_bf16': [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_long, c_int, c_int, c_int, c_int, c_int, _P],
     'drk_head_bwd_bf16': [_P, _P, _P, _P, _P, c_long, c_int, c_int, _P],
     'drk_conv_wgrad_bf16_multi': [_P, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, c_long, _P],
+    'drk_stem_wgrad_multi': [_P, _P, _P, c_int, _P, _P, c_int, c_int, _P],
     'drk_slab_reduce': [_P, c_int, c_long, _P, c_long, _P],
     'drk_slab_reduce2': [_P, c_int, c_long, _P, c_long, _P, _P],
     'drk_denoiser_fwd_bf16': [_P] * 16 + [c_int, c_int, c_int, _P, c_int, _P],

@@ -233,6 +233,8 @@ class GradSink:
         self.groups = {}                                 # sigma key -> (sigma, temb, acc [W])
         self.stem_dw = None
         self.stem_db = None
+        self.stem_records = []                           # (B, L, dpre [B,L,128], the call's input): the stem's gradients wait too
+        self.deferred_stem = False                       # set by grad_chain: a sink that outlives one backward call
 
     def group(self, key, sigma, temb):
         """The accumulator row of the forwards that ran at this sigma (key: its value as a Python number, known to the
@@ -285,7 +287,15 @@ class GradSink:
         g['final_conv.2.weight'] = hd[:V * C].view(V, C).unsqueeze(-1)
         g['final_conv.0.bias'] = hd[V * C:(V + 1) * C]
         g['final_conv.2.bias'] = hd[(V + 1) * C:(V + 1) * C + V]
-        # ---- stem
+        # ---- stem: the recorded calls of one shape and input kind in one launch
+        by_kind = {}
+        for B, L, dpre, seq in self.stem_records:
+            by_kind.setdefault((B, L, seq.dtype == torch.int64), []).append((dpre, seq))
+        for (B, L, tok), recs in by_kind.items():
+            dw_t, db = self.stem(dev)
+            ptrs = torch.tensor([[r[w].data_ptr() for r in recs] for w in (0, 1)], dtype=torch.int64,
+                                pin_memory=True).to(dev, non_blocking=True)
+            ops.stem_wgrad_multi(ptrs[0], ptrs[1], tok, len(recs), dw_t, db, B, L)
         if self.stem_dw is not None:
             g['linear.weight'] = self.stem_dw.permute(2, 1, 0)
             g['linear.bias'] = self.stem_db[0]
@@ -302,6 +312,7 @@ class GradSink:
         for i in range(n):
             g[f'time_layers.{i}.dense.weight'], g[f'time_layers.{i}.dense.bias'] = d_dense_w[i], d_dense_b[i]
         self.records, self.groups, self.time, self.stem_dw, self.stem_db = [], {}, {}, None, None
+        self.stem_records = []
         return g
 
 
@@ -331,6 +342,7 @@ def grad_chain(bb):
     """(sink, anchor) for a chain of differentiable bf16 forwards between two optimizer steps (the K Gumbel-softmax steps
     of _sample_finetune_gradient): pass both to backbone_with_grad(..., dtype='bf16', flat=anchor, sink=sink)."""
     sink = GradSink(bb)
+    sink.deferred_stem = True
     return sink, _ChainFn.apply(sink, *bb.parameters())
 
 
@@ -440,12 +452,15 @@ class _BackboneBf16Fn(torch.autograd.Function):
         kw = {}
         if want_w:
             P = ops.workspace(ops.denoiser_bwd_slabs(B, L) * sink.W * 4, dev)   # [slab][W]: every slot written by one launch
-            dw_t, db = sink.stem(dev)
-            kw = dict(partials=P, acc=sink.group(ctx.sigma_key, ctx.sigma, ctx.temb), stem_dw=dw_t, stem_db=db)
+            kw = dict(partials=P, acc=sink.group(ctx.sigma_key, ctx.sigma, ctx.temb))
+            if not sink.deferred_stem:
+                kw['stem_dw'], kw['stem_db'] = sink.stem(dev)
         ops.denoiser_bwd_bf16(dlogits, seq, pk, st, fastpath._packed_T(bb), ctx.tbias[0], ctx.feats, ctx.masks, ctx.means,
                               ctx.rstds, ctx.y, dcs, gr, dx=dseq, per_layer=ctx.per_layer, **kw)
         if want_w:
             sink.records.append((B, L, ctx.hs, dcs))
+            if sink.deferred_stem:
+                sink.stem_records.append((B, L, gr, seq))       # gr = dL/d(stem pre-activation) now
         ctx.feats = ctx.hs = ctx.masks = ctx.means = ctx.rstds = ctx.y = None
         if ctx.sink is not None or not want_w:        # the chain's _ChainFn hands the parameters their gradients
             return (None, dseq, None, None) + (None,) * len(ctx.needs_input_grad[4:])

@@ -97,7 +97,7 @@ extern "C" int drk_denoiser_bwd_bf16(const float* dlogits, const float* y, const
             "drk_denoiser_bwd_bf16");
   CARGCHECK(dcs_slots == n_layers + 1 || (dcs_slots == 2 && !partials), "drk_denoiser_bwd_bf16 (dcs: n_layers + 1 slots, or 2 "
             "without partials)");
-  CARGCHECK(!partials == !acc && (!partials || (stem_dw && stem_db)), "drk_denoiser_bwd_bf16 (partials, acc, stem_dw, stem_db come together)");
+  CARGCHECK(!partials == !acc && !stem_dw == !stem_db && (!stem_dw || partials), "drk_denoiser_bwd_bf16 (partials with acc, stem_dw with stem_db; the stem pair only with partials)");
   const long M = (long)B * L, n = n_layers;
   const long W = drk_denoiser_bwd_bf16_slab_floats(n_layers);
   const char* wt = (const char*)wstream_t;
@@ -116,7 +116,7 @@ extern "C" int drk_denoiser_bwd_bf16(const float* dlogits, const float* y, const
       float* tmp = partials + nown * W;             // the workspace's tail (drk_denoiser_bwd_bf16_slabs)
       TRY(drk_slab_reduce2(partials, 2 * B, W, acc, head_off, tmp, stream));
       TRY(drk_slab_reduce(partials + head_off, (int)((M + 127) / 128), W, acc + head_off, W - head_off, stream));
-      TRY(drk_colsum128(gr, stem_db, 1, M, stream));
+      if (stem_db) TRY(drk_colsum128(gr, stem_db, 1, M, stream));
     }
     if (stem_dw || dx) TRY(drk_stem_bwd(gr, x, x_soft, stem_w_t, stem_dw, dx, B, L, stream));
     return DRK_OK;
@@ -130,7 +130,7 @@ extern "C" int drk_denoiser_bwd_bf16(const float* dlogits, const float* y, const
   TRY(drk_relu_bwd(gr, feats, gr, M * DRK_C, stream));
   if (partials) {
     TRY(drk_slab_reduce(partials, (int)((M + 127) / 128), W, acc, W, stream));
-    TRY(drk_colsum128(gr, stem_db, 1, M, stream));
+    if (stem_db) TRY(drk_colsum128(gr, stem_db, 1, M, stream));
   }
   if (stem_dw || dx) TRY(drk_stem_bwd(gr, x, x_soft, stem_w_t, stem_dw, dx, B, L, stream));
   return DRK_OK;

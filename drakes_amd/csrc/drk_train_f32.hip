@@ -380,6 +380,70 @@ __global__ void __launch_bounds__(256) k_stem_wgrad(const float* __restrict__ dp
   }
 }
 
+// k_stem_wgrad over SEVERAL recorded backward calls in one launch (the chain's stem gradient, formed once: drakes_amd/
+// autograd.py::GradSink): workgroup = the same 64 rows of every segment, so the per-workgroup atomics are paid once per
+// chain, not once per call; db[co] += the column sums of dpre as well (what k_colsum128 adds per call).
+__global__ void __launch_bounds__(256) k_stem_wgrad_multi(const float* const* __restrict__ dpres, const int64_t* const* __restrict__ xs_tok,
+                                                          const float* const* __restrict__ xs_soft, int n_seg,
+                                                          float* __restrict__ dw_t, float* __restrict__ db, long M, int L) {
+  __shared__ float xs[(64 + 8) * DRK_V];
+  __shared__ float pw[2][DRK_TAPS * DRK_V + 1][DRK_C];
+  const long r0 = (long)blockIdx.x * 64;
+  const int co = threadIdx.x & 127, ph = threadIdx.x >> 7;
+  float acc[DRK_TAPS * DRK_V];
+#pragma unroll
+  for (int k = 0; k < DRK_TAPS * DRK_V; ++k) acc[k] = 0.f;
+  float bsum = 0.f;
+  for (int seg = 0; seg < n_seg; ++seg) {
+    const float* __restrict__ dpre = dpres[seg];
+    const int64_t* __restrict__ x = xs_tok ? xs_tok[seg] : nullptr;
+    const float* __restrict__ x_soft = xs_soft ? xs_soft[seg] : nullptr;
+    __syncthreads();   // the previous segment's readers of xs are done
+    for (int i = threadIdx.x; i < (64 + 8) * DRK_V; i += 256) {
+      const long r = r0 - 4 + i / DRK_V;
+      const int v = i % DRK_V;
+      float val = 0.f;
+      if (r >= 0 && r < M) val = x ? ((int)x[r] == v ? 1.f : 0.f) : x_soft[r * DRK_V + v];
+      xs[i] = val;
+    }
+    __syncthreads();
+    for (int rb = ph; rb < 64; rb += 16) {                 // 8 rows of dpre in flight per thread
+      float dv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const long row = r0 + rb + 2 * j;
+        dv[j] = row < M ? dpre[row * DRK_C + co] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int rr = rb + 2 * j;
+        const long row = r0 + rr;
+        if (row >= M) break;
+        const int p = (int)(row % L);
+        const float d = dv[j];
+        bsum += d;
+#pragma unroll
+        for (int t = 0; t < DRK_TAPS; ++t) {
+          const int pp = p + t - 4;
+          if (pp >= 0 && pp < L) {
+#pragma unroll
+            for (int v = 0; v < DRK_V; ++v) acc[t * DRK_V + v] += d * xs[(rr + t) * DRK_V + v];
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < DRK_TAPS * DRK_V; ++k) pw[ph][k][co] = acc[k];
+  pw[ph][DRK_TAPS * DRK_V][co] = bsum;
+  __syncthreads();
+  if (ph == 0) {
+#pragma unroll
+    for (int k = 0; k < DRK_TAPS * DRK_V; ++k) atomicAdd(dw_t + k * DRK_C + co, pw[0][k][co] + pw[1][k][co]);
+    if (db) atomicAdd(db + co, pw[0][DRK_TAPS * DRK_V][co] + pw[1][DRK_TAPS * DRK_V][co]);
+  }
+}
+
 // one wave per (row, all 5 v): lane = co pair; 9 taps; shuffle-reduce over the wave
 __global__ void __launch_bounds__(256) k_stem_dgrad(const float* __restrict__ dpre, const float* __restrict__ w_t,
                                                     float* __restrict__ dx, long M, int L) {
@@ -1020,6 +1084,22 @@ extern "C" int drk_stem_bwd(const float* dpre, const int64_t* x, const float* x_
     hipLaunchKernelGGL(k_stem_dgrad, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, dpre, w_t, dx, M, L);
     DRK_CHECK_LAUNCH();
   }
+  return DRK_OK;
+}
+
+// The stem's weight and bias gradients of n_seg recorded backward calls of one shape in one launch: dw_t [9][5][128] +=,
+// db [128] += (NULL: not wanted); dpre_ptrs / x_ptrs / x_soft_ptrs: DEVICE arrays of n_seg pointers to each call's dpre
+// [B*L][128] and its input (tokens int64 [B*L] through x_ptrs, or soft float32 [B*L][5] through x_soft_ptrs: one of the
+// two arrays, the other NULL).
+extern "C" int drk_stem_wgrad_multi(const float* const* dpre_ptrs, const int64_t* const* x_ptrs, const float* const* x_soft_ptrs,
+                                    int n_seg, float* dw_t, float* db, int B, int L, void* stream) {
+  DRK_SHAPE_GUARD("drk_stem_wgrad_multi");
+  if (n_seg == 0) return DRK_OK;
+  ARGCHECK(n_seg > 0 && dpre_ptrs && (!x_ptrs != !x_soft_ptrs) && dw_t, "drk_stem_wgrad_multi");
+  const long M = (long)B * L;
+  hipLaunchKernelGGL(k_stem_wgrad_multi, dim3((unsigned)((M + 63) / 64)), dim3(256), 0, (hipStream_t)stream, dpre_ptrs, x_ptrs,
+                     x_soft_ptrs, n_seg, dw_t, db, M, L);
+  DRK_CHECK_LAUNCH();
   return DRK_OK;
 }
 

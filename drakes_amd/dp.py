@@ -98,12 +98,10 @@ class GradBucket:
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
         self.attach()
 
-    def attach(self, flat=None):
-        """(Re)points every p.grad at its slice; call after anything that set grads to None.  flat: another buffer of the
-        bucket's size to collect the next backward passes in (fine_tune's lanes), default the bucket's own."""
-        flat = self.flat if flat is None else flat
+    def attach(self):
+        """(Re)points every p.grad at its slice; call after anything that set grads to None."""
         for p, off in zip(self.params, self.offsets):
-            p.grad = flat[off:off + p.numel()].view_as(p)
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
 
     def zero_(self):
         self.flat.zero_()

@@ -21,20 +21,11 @@ Same arguments and return value as the reference function.  Differences, all add
   * `kl_streams` (default 2; 0 = off): the frozen model's forwards of the KL term run round-robin on that many side
     streams, and autograd runs their input-gradient launches there too, beside the new model's backward chain (at
     fine-tune batch sizes one launch fills at most half of the chip); same values;
-  * `micro_streams` (default 2; 1 = off): the micro-steps of one accumulation window (`args.num_accum_steps`, 4 in the
-    reference) share the weights, so they are independent until the optimizer step: micro-step i runs (sampling, KL,
-    backward) on lane stream i mod micro_streams with its own flat gradient buffer, and the window's gradient is the sum
-    of the lanes' buffers in micro-step order — the value the one-stream loop accumulates when a lane holds one
-    micro-step.  The host enqueues one micro-step after the other; what overlaps is the GPU work of neighbouring ones,
-    each of which fills at most half of the chip at the reference's batch sizes.  Values that the reference reads back
-    per micro-step (losses, rewards) are read back at the end of the window instead.  Memory: one micro-step's saved
-    activations per lane;
   * under torch.distributed (drakes_amd.dp) every rank runs its own shard (`args.batch_size` rows per rank); the flat
     gradient bucket is all-reduced once, after the last accumulation micro-step and BEFORE clipping (:89-92).
 The reward models are the caller's torch modules (the gReLU model in the reference, oracle.py:230-262): outside the
 path, called as they are.
 """
-import contextlib
 import os
 
 import numpy as np
@@ -71,15 +62,29 @@ def kl_of_step(new_model, old_model, last_x, condt, move_chance_t, copy_flag, re
     return autograd.kl_step_with_grad(log_p_x0, log_p_x0_old, last_x, copy_flag, float(move_chance_t.reshape(-1)[0]))
 
 
-def old_model_forwards(old_model, steps, last_x_list, condt_list, n_streams, lane=0):
+def old_model_forwards(old_model, steps, last_x_list, condt_list, n_streams):
     """{step: old_model.forward(last_x[step], condt[step])} for the given steps, run round-robin on `n_streams` side
     streams: the forwards are independent of each other, and at fine-tune batch sizes (one workgroup per sequence, 32-128
     sequences) each fills at most half of the chip.  autograd runs each one's backward on the stream of its forward, so
     the frozen model's input-gradient launches overlap the new model's backward chain the same way.  The caller's
     stream waits for the side streams before this returns."""
     cur = torch.cuda.current_stream()
-    streams = _side_streams(cur.device, n_streams, ('kl', lane))
+    streams = _side_streams(cur.device, n_streams)
     out = {}
+    # whatever the frozen model caches per weight version (kernel-layout copies of its weights) is built HERE, on the
+    # caller's stream: built inside the first side-stream forward, the second stream would read it unordered
+    bb = old_model.backbone
+    pk = bb.packed()
+    soft = old_model.hip_soft_dtype or old_model.hip_dtype
+    if soft == 'bf16' and getattr(bb, 'width', 128) == 128:
+        from . import fastpath
+        fastpath._packed(bb)
+        fastpath._packed_T(bb)
+    else:
+        for k in ('conv_w', 'conv_wT', 'head0_w', 'head0_wT'):
+            pk[k]
+        if soft == 'bf16x3':
+            bb.packed_x3()
     for s in streams:
         s.wait_stream(cur)
     for k, t in enumerate(steps):
@@ -98,8 +103,8 @@ def old_model_forwards(old_model, steps, last_x_list, condt_list, n_streams, lan
 _STREAMS = {}
 
 
-def _side_streams(device, n, tag='kl'):
-    key = (device.index, n, tag)
+def _side_streams(device, n):
+    key = (device.index, n)
     if key not in _STREAMS:
         _STREAMS[key] = [torch.cuda.Stream(device=device) for _ in range(n)]
     return _STREAMS[key]
@@ -107,7 +112,7 @@ def _side_streams(device, n, tag='kl'):
 
 def fine_tune(new_model, new_model_y, new_model_y_eval, old_model, args, eps=1e-5, *, log_path=None, save_path=None,
               seed_of_call=None, verbose=True, on_update=None, skip_hard_step_kl=True,
-              reuse_sampling_forward=True, kl_streams=2, micro_streams=2):
+              reuse_sampling_forward=True, kl_streams=2):
     if log_path is not None:
         with open(log_path, 'w') as f:
             f.write(args.__repr__() + '\n')
@@ -126,88 +131,56 @@ def fine_tune(new_model, new_model_y, new_model_y_eval, old_model, args, eps=1e-
     batch_rewards = []
     call = 0
     rank, world = dp.rank(), dp.world()
-    dev0 = bucket.flat.device
-    n_lanes = max(1, min(int(micro_streams or 1), args.num_accum_steps)) if dev0.type == 'cuda' else 1
-    lanes, main_stream = None, None
-    if n_lanes > 1:
-        main_stream = torch.cuda.current_stream(dev0)
-        lanes = [(st, torch.zeros_like(bucket.flat)) for st in _side_streams(dev0, n_lanes, 'micro')]
-    # (the parameters' AccumulateGrad nodes live on the caller's stream; gradients arriving from a lane are synchronised
-    # by the autograd engine, which says so once per process unless told that it is meant)
-    warn_was = None
-    if (lanes is not None or kl_streams) and hasattr(torch.autograd.graph, 'set_warn_on_accumulate_grad_stream_mismatch'):
-        warn_was = True
-        torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
 
     for epoch_num in range(args.num_epochs):                                                  # :31
         rewards, rewards_eval, losses, reward_losses, kl_losses = [], [], [], [], []
         tot_grad_norm = 0.0
         new_model.train()
-        pending = []                            # device scalars of the window, read back after its optimizer step
         for _step in range(args.num_accum_steps):                                             # :39
             kw = {}
             if seed_of_call is not None:
                 kw['seed'] = seed_of_call(call)
             call += 1
-            lane = _step % n_lanes
-            if lanes is not None:
-                # this micro-step's launches go to its lane's stream and its gradients to its lane's buffer
-                if _step < n_lanes:
-                    lanes[lane][0].wait_stream(main_stream)
-                bucket.attach(lanes[lane][1])
-            with (torch.cuda.stream(lanes[lane][0]) if lanes is not None else contextlib.nullcontext()):
-                if lanes is not None and _step < n_lanes:
-                    lanes[lane][1].zero_()
-                sample, last_x_list, condt_list, move_chance_t_list, copy_flag_list = new_model._sample_finetune_gradient(
-                    eval_sp_size=args.batch_size, copy_flag_temp=args.copy_flag_temp,
-                    sample_offset=rank * args.batch_size, **kw)                               # :40, [bsz, seqlen, 4]
-                sample2 = torch.transpose(sample, 1, 2)
-                preds = new_model_y(sample2).squeeze(-1)                                      # [bsz, 3]
-                reward = preds[:, 0]
+            sample, last_x_list, condt_list, move_chance_t_list, copy_flag_list = new_model._sample_finetune_gradient(
+                eval_sp_size=args.batch_size, copy_flag_temp=args.copy_flag_temp,
+                sample_offset=rank * args.batch_size, **kw)                                   # :40, [bsz, seqlen, 4]
+            sample2 = torch.transpose(sample, 1, 2)
+            preds = new_model_y(sample2).squeeze(-1)                                          # [bsz, 3]
+            reward = preds[:, 0]
 
-                with torch.no_grad():                                                         # logging only (:45-55)
-                    sample_argmax = 1.0 * F.one_hot(torch.argmax(sample, 2), num_classes=4)
-                    sample_argmax = torch.transpose(sample_argmax, 1, 2)
-                    r_log = new_model_y(sample_argmax).squeeze(-1)[:, 0]
-                    r_eval_log = new_model_y_eval(sample_argmax).squeeze(-1)[:, 0]
+            with torch.no_grad():                                                             # logging only (:45-55)
+                sample_argmax = 1.0 * F.one_hot(torch.argmax(sample, 2), num_classes=4)
+                sample_argmax = torch.transpose(sample_argmax, 1, 2)
+                rewards.append(new_model_y(sample_argmax).squeeze(-1)[:, 0].cpu().numpy())
+                rewards_eval.append(new_model_y_eval(sample_argmax).squeeze(-1)[:, 0].cpu().numpy())
 
-                total_kl = []
-                kl_steps = [t for t in range(args.total_num_steps)                            # :60-75
-                            if not (args.truncate_kl and t < args.total_num_steps - args.truncate_steps)]
-                run_steps = [t for t in kl_steps if not (skip_hard_step_kl and copy_flag_list[t].dtype == torch.int64)]
-                old_logps = {}
-                if kl_streams and sample.is_cuda and len(run_steps) > 1:
-                    old_logps = old_model_forwards(old_model, run_steps, last_x_list, condt_list, kl_streams, lane)
-                for random_t in kl_steps:
-                    if skip_hard_step_kl and copy_flag_list[random_t].dtype == torch.int64:
-                        total_kl.append(torch.zeros(args.batch_size, dtype=torch.float32, device=sample.device))
-                        continue
-                    total_kl.append(kl_of_step(new_model, old_model, last_x_list[random_t], condt_list[random_t],
-                                               move_chance_t_list[random_t], copy_flag_list[random_t], reuse_sampling_forward,
-                                               old_logps.get(random_t)))
+            total_kl = []
+            kl_steps = [t for t in range(args.total_num_steps)                                # :60-75
+                        if not (args.truncate_kl and t < args.total_num_steps - args.truncate_steps)]
+            run_steps = [t for t in kl_steps if not (skip_hard_step_kl and copy_flag_list[t].dtype == torch.int64)]
+            old_logps = {}
+            if kl_streams and sample.is_cuda and len(run_steps) > 1:
+                old_logps = old_model_forwards(old_model, run_steps, last_x_list, condt_list, kl_streams)
+            for random_t in kl_steps:
+                if skip_hard_step_kl and copy_flag_list[random_t].dtype == torch.int64:
+                    total_kl.append(torch.zeros(args.batch_size, dtype=torch.float32, device=sample.device))
+                    continue
+                total_kl.append(kl_of_step(new_model, old_model, last_x_list[random_t], condt_list[random_t],
+                                           move_chance_t_list[random_t], copy_flag_list[random_t], reuse_sampling_forward,
+                                           old_logps.get(random_t)))
 
-                if epoch_num < args.alpha_schedule_warmup:                                    # :77-81, linear warm-up
-                    current_alpha = (epoch_num + 1) / args.alpha_schedule_warmup * args.alpha
-                else:
-                    current_alpha = args.alpha
+            if epoch_num < args.alpha_schedule_warmup:                                        # :77-81, linear warm-up
+                current_alpha = (epoch_num + 1) / args.alpha_schedule_warmup * args.alpha
+            else:
+                current_alpha = args.alpha
 
-                kl_loss = torch.stack(total_kl, 1).sum(1).mean()                              # :83-86
-                reward_loss = -torch.mean(reward)
-                loss = reward_loss + kl_loss * current_alpha
-                loss = loss / args.num_accum_steps
+            kl_loss = torch.stack(total_kl, 1).sum(1).mean()                                  # :83-86
+            reward_loss = -torch.mean(reward)
+            loss = reward_loss + kl_loss * current_alpha
+            loss = loss / args.num_accum_steps
 
-                loss.backward()
-                pending.append((loss.detach(), torch.mean(reward).detach(), reward_loss.detach(), kl_loss.detach(), r_log,
-                                r_eval_log))
+            loss.backward()
             if (_step + 1) % args.num_accum_steps == 0:                                       # :89-93
-                if lanes is not None:
-                    # the window's gradient: the lanes' buffers added in micro-step order, on the caller's stream
-                    for st, _ in lanes[:min(n_lanes, args.num_accum_steps)]:
-                        main_stream.wait_stream(st)
-                    bucket.attach()
-                    bucket.flat.zero_()
-                    for _, flat in lanes[:min(n_lanes, args.num_accum_steps)]:
-                        bucket.flat.add_(flat)
                 bucket.allreduce_mean_()
                 if on_update is not None:
                     on_update(new_model, epoch_num)
@@ -215,15 +188,12 @@ def fine_tune(new_model, new_model_y, new_model_y_eval, old_model, args, eps=1e-
                 tot_grad_norm += float(norm)
                 optim.step()
                 bucket.zero_()                  # optim.zero_grad() would drop the views
-                for lo, rm, rl, kl, r_log, r_eval_log in pending:
-                    rewards.append(r_log.cpu().numpy())
-                    rewards_eval.append(r_eval_log.cpu().numpy())
-                    batch_losses.append(lo.cpu().numpy())
-                    batch_rewards.append(rm.cpu().numpy())
-                    losses.append(lo.cpu().numpy() * args.num_accum_steps)
-                    reward_losses.append(rl.cpu().numpy())
-                    kl_losses.append(kl.cpu().numpy())
-                pending = []
+
+            batch_losses.append(loss.cpu().detach().numpy())
+            batch_rewards.append(torch.mean(reward).cpu().detach().numpy())
+            losses.append(loss.cpu().detach().numpy() * args.num_accum_steps)
+            reward_losses.append(reward_loss.cpu().detach().numpy())
+            kl_losses.append(kl_loss.cpu().detach().numpy())
 
         rewards, rewards_eval = np.array(rewards), np.array(rewards_eval)
         line = (f'Epoch {epoch_num} Mean reward {np.mean(rewards)} Mean reward eval {np.mean(rewards_eval)} '
@@ -238,8 +208,6 @@ def fine_tune(new_model, new_model_y, new_model_y_eval, old_model, args, eps=1e-
             torch.save(new_model.state_dict(), os.path.join(save_path, f'model_{epoch_num}.ckpt'))
     for p, f in zip(old_model.parameters(), old_flags):
         p.requires_grad_(f)
-    if warn_was:
-        torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(True)
     fine_tune.last_log = dict(tot_grad_norm=tot_grad_norm, mean_reward=float(np.mean(rewards)),
                               mean_kl=float(np.mean(kl_losses)))
     return batch_losses

@@ -485,6 +485,14 @@ def denoiser_bwd_bf16(dlogits, seq, pk, st, wstream_t, tbias, feats, masks, mean
               _f(stem_dw, 'stem_dw'), _f(stem_db, 'stem_db'), _f(dx, 'dx'), B, L, n, st['dil'], fl, _stream())
 
 
+def stem_wgrad_multi(dpre_ptrs, x_ptrs, tokens, n_seg, dw_t, db, B, L):
+    """drk_stem_wgrad_multi: dw_t [9,5,128] += and db [1,128] += over n_seg recorded calls; dpre_ptrs / x_ptrs: int64
+    device tensors of n_seg addresses (x: token tensors when `tokens`, else soft [B,L,5] tensors)."""
+    xp = _i(x_ptrs, 'x_ptrs')
+    _lib.call('drk_stem_wgrad_multi', _i(dpre_ptrs, 'dpre_ptrs'), xp if tokens else None, None if tokens else xp, n_seg,
+              _f(dw_t, 'dw_t'), _f(db, 'db'), B, L, _stream())
+
+
 def denoiser_bwd_slabs(B, L):
     """Partial slabs drk_denoiser_bwd_bf16 wants in its workspace."""
     return int(_lib.load().drk_denoiser_bwd_bf16_slabs(B, L))

@@ -194,6 +194,12 @@ int drk_head_out_bwd(const float* dlogits, const float* y, const float* w, float
  * (NULL for token input: no gradient flows into integer tokens). */
 int drk_stem_bwd(const float* dpre, const int64_t* x, const float* x_soft, const float* w_t, float* dw_t,
                  float* dx, int B, int L, void* stream);
+/* The stem's weight and bias gradients (models/dnaconv.py:80-86 under torch autograd) of n_seg recorded backward calls of
+ * one shape in ONE launch: dw_t [9][5][128] +=, db [128] += (NULL: not wanted).  dpre_ptrs, x_ptrs, x_soft_ptrs: DEVICE
+ * arrays of n_seg pointers — each call's dpre [B*L][128] and its input, tokens int64 [B*L] (x_ptrs) or soft float32
+ * [B*L][5] (x_soft_ptrs): exactly one of the two arrays, the other NULL. */
+int drk_stem_wgrad_multi(const float* const* dpre_ptrs, const int64_t* const* x_ptrs, const float* const* x_soft_ptrs,
+                         int n_seg, float* dw_t, float* db, int B, int L, void* stream);
 /* Backward of drk_time_bias_fwd + drk_time_embed_fwd from dtbias [nb][n_layers][128]; all outputs accumulated.
  * dtemb: float32 [nb][128] scratch, ZEROED by the caller (the layers' contributions to the embedding gradient meet there). */
 int drk_time_bwd(const float* dtbias, const float* sigma, int nb, const float* W, const float* temb,
@@ -416,7 +422,9 @@ int drk_train_fwd_fused_bf16(const void* wstream, const float* vecs, const float
  * slabs of drk_denoiser_bwd_bf16_slab_floats(n_layers) floats — slot i < n_layers: layer i's [4][128] of
  * drk_layer_bwd_bf16, slot n_layers: final_conv.0's input-gradient launch, then drk_head_bwd_bf16's slab — summed in
  * order into acc (+=, same length); stem_dw [9][5][128], stem_db [128] (+=, atomics); dx float32 [B*L][5] (x_soft only,
- * may be NULL).  partials, acc, stem_dw, stem_db: all or none. */
+ * may be NULL).  partials and acc come together; stem_dw and stem_db come together and only with partials — a caller that
+ * keeps every call's gr (= dL/d stem pre-activation on return) leaves them NULL and forms the stem's gradients once per
+ * chain with drk_stem_wgrad_multi. */
 long drk_denoiser_bwd_bf16_slab_floats(int n_layers);
 long drk_denoiser_bwd_bf16_slabs(int B, int L);
 int drk_denoiser_bwd_bf16(const float* dlogits, const float* y, const float* head2_w, const void* wstream_t,

@@ -165,8 +165,9 @@ def test_native_denoiser_entry_points_reject_bad_arguments():
         (bwd(dlogits=None), 'bad arguments'),
         (bwd(slots=3), 'dcs'),
         (bwd(slots=2), 'dcs'),                      # two slots only without parameter-gradient partials
-        (bwd(acc=None), 'come together'),
-        (bwd(stem_db=None), 'come together'),
+        (bwd(acc=None), 'partials with acc'),
+        (bwd(stem_db=None), 'stem_dw with stem_db'),
+        (bwd(partials=None, acc=None, slots=2), 'only with partials'),
         (bwd(L=-3), 'bad shape'),
         (('drk_train_fwd_fused_bf16', P, P, P, P, P, P, P, P, P, P, 2, 225, 20, dp, None), 'L <= 224'),
         (('drk_train_fwd_fused_bf16', P, P, P, P, P, P, P, P, P, P, 2, 200, 21, dp, None), 'L <= 224'),

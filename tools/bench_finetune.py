@@ -36,8 +36,7 @@ def loop(a):
     for r in range(a.reps + 1):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        drakes_amd.fine_tune(new_model, reward, reward, old_model, args, verbose=False, **({'kl_streams': a.kl_streams} if a.kl_streams is not None else {}),
-                             **({'micro_streams': a.micro_streams} if a.micro_streams is not None else {}))
+        drakes_amd.fine_tune(new_model, reward, reward, old_model, args, verbose=False, **({'kl_streams': a.kl_streams} if a.kl_streams is not None else {}))
         torch.cuda.synchronize()
         ts.append(time.perf_counter() - t0)
         print(f'rep {r}: {ts[-1]:.3f} s per optimizer step', flush=True)
@@ -61,7 +60,6 @@ def main():
     ap.add_argument('--dtype', default='fp32', choices=['fp32', 'bf16x3', 'bf16'], help="hip_dtype: 'bf16' = fused hard phase + bf16 soft steps and backward; 'bf16x3' = fp32-grade convolutions on bf16 MFMA")
     ap.add_argument('--loop', action='store_true', help='time whole fine_tune optimizer steps (sampling + reward + KL over all steps + Adam)')
     ap.add_argument('--accum', type=int, default=1, help='--loop: micro-steps per optimizer step (the reference default is 4)')
-    ap.add_argument('--micro-streams', type=int, default=None, help='fine_tune(micro_streams=...): lanes of an accumulation window (1: none)')
     ap.add_argument('--kl-streams', type=int, default=None, help='fine_tune(kl_streams=...): side streams of the frozen model (0: none)')
     a = ap.parse_args()
     if a.loop:

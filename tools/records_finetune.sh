@@ -17,7 +17,5 @@ timeout -k 10 200 python tools/bench_finetune.py --dtype bf16 --batch 128 --reps
 timeout -k 10 200 python tools/bench_finetune.py --dtype bf16 --batch 32 --reps 3 --json $o/finetune_c3_b32.json > /dev/null 2>&1
 timeout -k 10 200 python tools/bench_finetune.py --dtype bf16 --batch 128 --reps 4 --loop --json $o/finetune_loop_b128.json > /dev/null 2>&1
 timeout -k 10 200 python tools/bench_finetune.py --dtype bf16 --batch 32 --reps 4 --loop --json $o/finetune_loop_b32.json > /dev/null 2>&1
-timeout -k 10 300 python tools/bench_finetune.py --dtype bf16 --batch 32 --reps 3 --loop --accum 4 --json $o/finetune_loop_b32_accum4.json > /dev/null 2>&1
-timeout -k 10 300 python tools/bench_finetune.py --dtype bf16 --batch 128 --reps 3 --loop --accum 4 --json $o/finetune_loop_b128_accum4.json > /dev/null 2>&1
 grep -h "seconds_per_step\|total_s" $o/finetune_*.json
 cut -c200-330 $o/bench_finetune_line.json; cut -c200-330 $o/bench_finetune_b32_line.json
