@@ -540,3 +540,37 @@ def test_fused_train_backward_matches_per_layer_launches(dev, det_sd, B, L, soft
     for k, v in worst.items():
         if k != 'acc':
             assert v <= 1e-2, (k, v)
+
+
+@pytest.mark.parametrize('tokens', [False, True])
+def test_stem_wgrad_multi_kernel(dev, tokens):
+    """drk_stem_wgrad_multi: the stem's weight and bias gradients of several recorded calls in one launch against
+    drk_stem_bwd + drk_colsum128 call by call (fp32 atomics both ways: summation order only), soft and token input;
+    B*L not a multiple of the 64-row workgroup."""
+    gen = torch.Generator().manual_seed(3)
+    B, L, n_seg = 3, 77, 4
+    w_t = torch.randn(9, 5, 128, generator=gen).to(dev)
+    dpres = [torch.randn(B, L, 128, generator=gen).to(dev) for _ in range(n_seg)]
+    if tokens:
+        xs = [torch.randint(0, 5, (B, L), generator=gen).to(dev) for _ in range(n_seg)]
+    else:
+        xs = [torch.softmax(torch.randn(B, L, 5, generator=gen), -1).to(dev) for _ in range(n_seg)]
+    dw_ref = torch.zeros(9, 5, 128, device=dev)
+    db_ref = torch.zeros(1, 128, device=dev)
+    for d, x in zip(dpres, xs):
+        ops.stem_bwd(d, x, w_t, dw_ref, None if tokens else torch.empty(B, L, 5, device=dev))
+        ops.colsum128(d, 1, B * L, db_ref)
+    dw = torch.zeros(9, 5, 128, device=dev)
+    db = torch.zeros(1, 128, device=dev)
+    ptrs = torch.tensor([[t.data_ptr() for t in dpres], [t.data_ptr() for t in xs]], dtype=torch.int64).to(dev)
+    ops.stem_wgrad_multi(ptrs[0], ptrs[1], tokens, n_seg, dw, db, B, L)
+    torch.testing.assert_close(dw, dw_ref, rtol=1e-5, atol=1e-4)
+    torch.testing.assert_close(db, db_ref, rtol=1e-5, atol=1e-4)
+    with torch.no_grad():                      # and against plain torch: dW[t][v][c] = sum_rows dpre[r][c] * x[r + t - 4][v]
+        oh = [torch.nn.functional.one_hot(x, 5).float() if tokens else x for x in xs]
+        want = torch.zeros(9, 5, 128, device=dev)
+        for d, x in zip(dpres, oh):
+            xp = torch.nn.functional.pad(x, (0, 0, 4, 4))
+            for t in range(9):
+                want[t] += torch.einsum('blv,blc->vc', xp[:, t:t + L], d)
+    torch.testing.assert_close(dw, want, rtol=1e-4, atol=1e-3)
