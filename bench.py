@@ -48,15 +48,15 @@ PEAK = {'bf16': 2500.0, 'fp32': 157.3}            # TFLOP/s dense MFMA, MI355X_M
 # for 16-B-per-lane loads on gfx950): tools/pmc_traffic.sh.  A recorded measurement (a process cannot collect PMC
 # counters on itself): it names the library version it was taken on and is printed ONLY when drk_version() still is
 # that version — a changed kernel reports traffic null until the passes are re-run.
-PMC_TRAFFIC = {('bf16', 1024): {'drk_version': 310,
-                                'bytes_per_launch': 27219477952.0, 'fetch_bytes': 26716472320.0, 'write_bytes': 503005632.0,
+PMC_TRAFFIC = {('bf16', 1024): {'drk_version': 311,
+                                'bytes_per_launch': 27219465664.0, 'fetch_bytes': 26716473088.0, 'write_bytes': 502992576.0,
                                 'algorithmic_bytes': 7.6e6,
                                 'note': 'L2-to-fabric requests; Infinity-Cache hits are counted: the 5.9 MB bf16 weight '
                                         'stream outgrows a 4 MB per-XCD L2 and is re-fetched from the 256 MB Infinity '
                                         'Cache; 0.25 TB/s = 3.1 % of HBM peak, the launch is MFMA-bound; the writes are '
                                         'scratch spills of the per-forward stem/head block (140 B/lane reserved; 2 dwords per lane and forward '
                                         'actually written), tokens out are 1.6 MB',
-                                'source': 'profiles/r3_bf16_v310_pmc_traffic.json'}}
+                                'source': 'profiles/r3_bf16_v311_pmc_traffic.json'}}
 
 
 def _median(v):
@@ -263,8 +263,8 @@ def secondary_fp32(model, B=1024, dtype='fp32'):
 
 
 # The dominant launch of configs[4] (k_group_bf16<8,true>: layers 8..19 + head, B=256, L=1024): tools/pmc_group.sh,
-# profiles/r3_group_v310_pmc.json.  Printed only while drk_version() is the version it was taken on.
-PMC_TRAFFIC_LONG = {'drk_version': 310, 'bytes_per_launch': 385431424.0, 'fetch_bytes': 303639296.0, 'write_bytes': 81792128.0,
+# profiles/r3_group_v311_pmc.json.  Printed only while drk_version() is the version it was taken on.
+PMC_TRAFFIC_LONG = {'drk_version': 311, 'bytes_per_launch': 386126464.0, 'fetch_bytes': 303667968.0, 'write_bytes': 82458496.0,
                     'launch': 'the largest of the three: layers 8..19 + head, stride 4 (the two halo launches: 360 MB each)',
                     'algorithmic_bytes': 256 * 1024 * (512 + 20.0),
                     'note': 'L2-to-fabric requests (FETCH_SIZE doubled per MI355X_MICROARCH.md); beyond the 134 MB of residual '

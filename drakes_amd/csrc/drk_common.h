@@ -9,7 +9,7 @@
 #define DRK_TAPS 9       // Conv1d kernel_size        (models/dnaconv.py:53-57)
 #define DRK_NEG_INF (-1000000.0f)   // diffusion_gosai_update.py:127
 #define DRK_MAX_DEVICES 64   // per-device set-up flags (one node holds 8 GPUs)
-#define DRK_VERSION 310     // bump whenever a kernel changes: bench.py ties recorded PMC traffic to it, every bench line carries it
+#define DRK_VERSION 311     // bump whenever a kernel changes: bench.py ties recorded PMC traffic to it, every bench line carries it
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
